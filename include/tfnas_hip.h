@@ -1,0 +1,171 @@
+/*
+ * tfnas_hip.h -- C ABI of the MI355X (gfx950) hot path of the TF-NAS supernet search step.
+ *
+ * The reference has NO native/FFI boundary for this path: its boundary is the Python
+ * nn.Module API of models/model_search.py.  This header is therefore the boundary *we* define below that
+ * API: the Python modules in tf-nas_amd/tfnas_amd/model_search.py (same class names, constructor and
+ * forward(x, sampling, mode) signatures as the reference) call these entry points through ctypes with raw
+ * device pointers.  Each entry point cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - all tensors are fp32, activations are NHWC ("channels_last"): x[n][h][w][c], c fastest;
+ *  - the caller (PyTorch) owns and allocates every buffer, including saved-for-backward tensors and
+ *    scratch; sizes come from tfnas_cell_ws();
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - return value: 0 ok, <0 invalid argument (TFNAS_E*), >0 a hipError_t;
+ *  - no global mutable state; re-entrant per stream.
+ *
+ * A "cell" is one MixedOP (18 per network); its G "groups" are the MBConv candidates evaluated in this
+ * call: G = 8 in the soft (alpha-step) mode, G = 1 in the sampled (w-step) mode.  All groups' expanded
+ * channels live side by side in one [pixels][M] tensor (M = sum of padded mid widths) so that the 1x1
+ * expand of all candidates is ONE GEMM and every per-channel pass (BN statistics, depthwise, SE) runs
+ * once over the concatenation.
+ */
+#ifndef TFNAS_HIP_H
+#define TFNAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFNAS_ABI_VERSION 1
+#define TFNAS_MAX_GROUPS 8
+#define TFNAS_MAX_SINK 4
+#define TFNAS_MAX_CELLS 32
+
+#define TFNAS_ACT_RELU 0
+#define TFNAS_ACT_SWISH 1
+
+#define TFNAS_EINVAL (-1)   /* bad geometry / alignment (ic, oc must be multiples of 4) */
+#define TFNAS_ENULL (-2)    /* required pointer is NULL */
+#define TFNAS_ERANGE (-3)   /* count out of range */
+
+/* One MBConv candidate (reference: MBInvertedResBlock, models/layers.py:431-561).  Weight pointers are
+ * the reference's OIHW nn.Parameter storages used as-is:
+ *   w_expand [mc][ic]      inverted_bottleneck.conv.weight  [mc,ic,1,1]
+ *   w_dw     [mc][k*k]     depth_conv.conv.weight           [mc,1,k,k]
+ *   w_proj   [oc][mc]      point_linear.conv.weight         [oc,mc,1,1]
+ *   w_se_r   [se][mc], b_se_r [se]   squeeze_excite.conv_reduce.{weight,bias}
+ *   w_se_e   [mc][se], b_se_e [mc]   squeeze_excite.conv_expand.{weight,bias}
+ * g_* are the matching gradient outputs (same shapes), only read/written when need_wgrad != 0. */
+typedef struct TfnasGroup {
+    int32_t mc;       /* mid channels (any integer > 0, e.g. 53)            [in]  */
+    int32_t k;        /* depthwise kernel size: 3 or 5                      [in]  */
+    int32_t se;       /* squeeze-excite width, 0 = no SE                    [in]  */
+    int32_t mcp;      /* mc rounded up to a multiple of 4                   [plan] */
+    int32_t off;      /* first column of this group in the [.][M] tensors   [plan] */
+    int32_t se_off;   /* first column in the [N][SE] hidden tensors         [plan] */
+    int32_t pad0, pad1;
+    const float *w_expand, *w_dw, *w_proj, *w_se_r, *b_se_r, *w_se_e, *b_se_e;
+    float *g_expand, *g_dw, *g_proj, *g_se_r, *gb_se_r, *g_se_e, *gb_se_e;
+} TfnasGroup;
+
+typedef struct TfnasCellDesc {
+    int32_t N, H, W;          /* input batch / height / width                       [in] */
+    int32_t ic, oc;           /* cell in/out channels (multiples of 4)              [in] */
+    int32_t stride;           /* 1 or 2 (depthwise stride; pad = k/2)               [in] */
+    int32_t act;              /* TFNAS_ACT_*                                        [in] */
+    int32_t has_res;          /* 1 when ic==oc && stride==1 (layers.py:537)         [in] */
+    int32_t G;                /* number of groups, 1..8                             [in] */
+    int32_t need_wgrad;       /* backward also produces weight gradients            [in] */
+    int32_t Ho, Wo;           /* output height / width                              [plan] */
+    int32_t M;                /* sum of mcp over groups                             [plan] */
+    int32_t SE;               /* sum of se over groups                              [plan] */
+    float eps;                /* BatchNorm eps (1e-5)                               [in] */
+    int32_t pad0;
+    TfnasGroup g[TFNAS_MAX_GROUPS];
+} TfnasCellDesc;
+
+/* Element counts / offsets of every caller-allocated buffer of one cell. */
+typedef struct TfnasCellWs {
+    /* forward (saved for backward) */
+    uint64_t E;        /* floats  [N*H*W][M]      raw 1x1-expand output (pre-BN)            */
+    uint64_t D;        /* floats  [N*Ho*Wo][M]    raw depthwise output (pre-BN)             */
+    uint64_t Pr;       /* floats  [G][N*Ho*Wo][oc] raw 1x1-project outputs (pre-BN)         */
+    uint64_t fsmall;   /* floats  pooled[N][M] | gate[N][M] | hpre[N][SE]                   */
+    uint64_t off_pooled, off_gate, off_hpre;
+    uint64_t stats;    /* doubles stats1[M][2] | stats2[M][2] | stats3[G*oc][2]  (sum,sumsq) */
+    uint64_t off_stats1, off_stats2, off_stats3;
+    uint64_t out;      /* floats  [N*Ho*Wo][oc]                                             */
+    /* backward scratch */
+    uint64_t dZ;       /* floats  [N*Ho*Wo][M]                                              */
+    uint64_t dEh;      /* floats  [N*H*W][M]                                                */
+    uint64_t bsmall;   /* floats  dgate[N][M] | dpooled[N][M] | dgl[N][M] | dhpre[N][SE] | cb1[M][4] */
+    uint64_t off_dgate, off_dpooled, off_dgl, off_dhpre, off_cb1;
+    uint64_t red;      /* doubles red3[G*oc][2] | red2[M][2] | red1[M][2]                   */
+    uint64_t off_red3, off_red2, off_red1;
+    uint64_t dx;       /* floats  [N*H*W][ic]                                               */
+} TfnasCellWs;
+
+int tfnas_abi_version(void);
+
+/* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs. */
+uint64_t tfnas_sizeof(int which);
+
+/* Fill the [plan] fields of a descriptor from its [in] fields.  Returns TFNAS_E* on bad geometry. */
+int tfnas_cell_plan(TfnasCellDesc *d);
+
+/* Buffer sizes for a planned descriptor. */
+int tfnas_cell_ws(const TfnasCellDesc *d, TfnasCellWs *ws);
+
+/* MixedOP forward.
+ *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):
+ *       out = sum_g wmix[g] * (BN3(project_g(SE_g(act(BN2(dw_g(act(BN1(expand_g(x))))))))) [+ x])
+ *       replaces MixedOP.forward soft branch, models/model_search.py:86-91 (line 89)
+ *   sampled mode (G=1, wmix = NULL meaning weight 1):
+ *       out = m_ops[idx](x);  replaces models/model_search.py:84-85 -> MBInvertedResBlock.forward layers.py:539-561
+ * BN everywhere = batch statistics, biased variance, no affine (layers.py:469,498,533). */
+int tfnas_mixedop_fwd(const TfnasCellDesc *d, const float *x, const float *wmix,
+                      float *E, float *D, float *Pr, float *fsmall, double *stats,
+                      float *out, void *stream);
+
+/* MixedOP backward (what autograd does for the graph above).  Produces dx [N*H*W][ic], dwmix[G]
+ * (d loss / d wmix[g]; may be NULL in sampled mode) and, when d->need_wgrad, the g_* weight gradients
+ * (overwritten, not accumulated).  dZ/dEh/bsmall/red are scratch. */
+int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
+                      const float *E, const float *D, const float *Pr, const float *fsmall,
+                      const double *stats, const float *dout,
+                      float *dZ, float *dEh, float *bsmall, double *red,
+                      float *dx, float *dwmix, void *stream);
+
+/* Gumbel-softmax over the candidates of `ncell` cells in one launch + expected cell latency.
+ *   w[c][i] = softmax_i((log_alpha[c][i] - log(e[c][i])) / T)      (F.gumbel_softmax, model_search.py:87)
+ *   cell_lat[c] = sum_i w[c][i] * lat[c][i]                          (model_search.py:90)
+ * log_alpha: `ncell` device pointers (each float[8]) -- the reference keeps one nn.Parameter per cell.
+ * e: Exp(1) draws, lat: looked-up latencies (model_search.py:93-111), both device float[ncell][8]. */
+int tfnas_arch_fwd(int ncell, const float *const *log_alpha, const float *e, const float *lat, float T,
+                   float *w, float *cell_lat, void *stream);
+
+/* Backward of tfnas_arch_fwd: dla[c][j] = (1/T) w_j (gt_j - sum_i gt_i w_i), gt_i = dw[c][i] + dlat[c]*lat[c][i].
+ * dlog_alpha: `ncell` device pointers receiving float[8] each. */
+int tfnas_arch_bwd(int ncell, const float *w, const float *lat, const float *dw, const float *dcell_lat,
+                   float T, float *const *dlog_alpha, void *stream);
+
+/* Sampled-mode index selection for `ncell` cells (model_search.py:59-81):
+ *   mode 0 'gumbel'/'gumbel_2': pos = argmax gumbel_softmax(log_softmax(log_alpha[mask]), T)
+ *   mode 1 'min_alphas', mode 2 'max_alphas': argmin / argmax of log_alpha[mask]
+ * mask: device uint8[ncell][8] (the `switches`); pos_out: device int32[ncell] = position among the
+ * switched-on candidates (the caller maps it like fink_ori_idx, model_search.py:49-56). */
+int tfnas_arch_sample(int ncell, const float *const *log_alpha, const uint8_t *mask, const float *e, float T,
+                      int mode, int32_t *pos_out, void *stream);
+
+/* Sink-connecting stage output (MixedStage.forward tail, models/model_search.py:202-204):
+ *   bw = softmax(betas[K]);  out = sum_k bw[k]*res[k];  out_lat = sum_k bw[k]*(cell_lat[0]+..+cell_lat[k])
+ * res: K device pointers to [count] floats each; cell_lat: device float[K] or NULL (sampled mode: lat 0).
+ * bw_out: device float[K] (saved for backward). */
+int tfnas_sink_fwd(int K, const float *betas, const float *const *res, const float *cell_lat,
+                   uint64_t count, float *out, float *out_lat, float *bw_out, void *stream);
+
+/* Backward of tfnas_sink_fwd: dres[k] = bw[k]*dout; dbetas via the softmax Jacobian of
+ * (<dout,res[k]> + dlat*cum_k); dcell_lat[j] = dlat * sum_{k>=j} bw[k].  dot_scratch: device double[K]. */
+int tfnas_sink_bwd(int K, const float *bw, const float *const *res, const float *cell_lat, const float *dout,
+                   const float *dlat, uint64_t count, float *const *dres, float *dbetas, float *dcell_lat,
+                   double *dot_scratch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFNAS_HIP_H */

@@ -64,13 +64,15 @@ def mbconv_forward(x, p, k, stride, act, has_res, detail=None):
     y = x
     if p.get('expand') is not None:
         e = F.conv2d(y, p['expand'])
+        eh = _bn(e)
         if detail is not None:
-            detail['E'] = e
-        y = _act(_bn(e), act)
+            detail['E'], detail['Eh'] = e, eh
+        y = _act(eh, act)
     d = F.conv2d(y, p['dw'], None, stride, k // 2, 1, p['dw'].shape[0])
+    dh = _bn(d)
     if detail is not None:
-        detail['D'] = d
-    y = _act(_bn(d), act)
+        detail['D'], detail['Dh'] = d, dh
+    y = _act(dh, act)
     if p.get('se_rw') is not None:
         pooled = F.adaptive_avg_pool2d(y, 1)
         hidden = _act(F.conv2d(pooled, p['se_rw'], p['se_rb']), act)
@@ -91,7 +93,10 @@ def gumbel_softmax(logits, tau, exp_noise=None):
     """softmax((logits - log(e)) / tau) with e ~ Exp(1); same arithmetic as torch's F.gumbel_softmax
     (hard=False).  ``exp_noise`` injects the e draws; None draws from torch's default generator in the
     same way torch does (so a seeded run reproduces the reference's RNG stream)."""
-    e = torch.empty_like(logits).exponential_() if exp_noise is None else exp_noise.to(logits.dtype)
+    if exp_noise is None:
+        e = torch.empty_like(logits).exponential_()
+    else:
+        e = exp_noise[..., :logits.shape[-1]].to(logits.dtype)
     gumbels = -e.log()
     return ((logits + gumbels) / tau).softmax(-1)
 

@@ -1,0 +1,194 @@
+// extern "C" surface of libtfnas_hip.so (declared in include/tfnas_hip.h): descriptor planning, workspace
+// sizing and the per-cell forward / backward launch sequences.
+#include <string.h>
+#include "tfnas_dev.h"
+#include "kernels.h"
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
+
+extern "C" uint64_t tfnas_sizeof(int which) {
+    return which == 0 ? sizeof(TfnasGroup) : which == 1 ? sizeof(TfnasCellDesc) : which == 2 ? sizeof(TfnasCellWs) : 0;
+}
+
+extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
+    if (!d) return TFNAS_ENULL;
+    if (d->G < 1 || d->G > TFNAS_MAX_GROUPS) return TFNAS_ERANGE;
+    if (d->N < 1 || d->H < 1 || d->W < 1 || d->ic < 4 || d->oc < 4) return TFNAS_EINVAL;
+    if ((d->ic & 3) || (d->oc & 3)) return TFNAS_EINVAL;
+    if (d->oc > 1024) return TFNAS_EINVAL;
+    if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
+    if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
+    if (d->has_res && (d->ic != d->oc || d->stride != 1)) return TFNAS_EINVAL;
+    // conv output size with pad = k/2 (same for k = 3 and 5)
+    d->Ho = (d->H - 1) / d->stride + 1;
+    d->Wo = (d->W - 1) / d->stride + 1;
+    int off = 0, se_off = 0;
+    for (int g = 0; g < d->G; ++g) {
+        TfnasGroup& gr = d->g[g];
+        if (gr.mc < 1 || (gr.k != 3 && gr.k != 5) || gr.se < 0) return TFNAS_EINVAL;
+        gr.mcp = (gr.mc + 3) & ~3;
+        gr.off = off;
+        gr.se_off = se_off;
+        off += gr.mcp;
+        se_off += gr.se;
+    }
+    d->M = off;
+    d->SE = se_off;
+    if ((double)d->N * d->H * d->W >= 2147483647.0) return TFNAS_ERANGE;   // row indices are int, offsets size_t
+    return 0;
+}
+
+extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
+    if (!d || !ws) return TFNAS_ENULL;
+    memset(ws, 0, sizeof(*ws));
+    const uint64_t P = (uint64_t)d->N * d->H * d->W, Po = (uint64_t)d->N * d->Ho * d->Wo;
+    const uint64_t M = d->M, N = d->N, SE = d->SE, G = d->G, oc = d->oc;
+    ws->E = P * M;
+    ws->D = Po * M;
+    ws->Pr = G * Po * oc;
+    ws->off_pooled = 0;
+    ws->off_gate = N * M;
+    ws->off_hpre = 2 * N * M;
+    ws->fsmall = 2 * N * M + N * SE + 4;
+    ws->off_stats1 = 0;
+    ws->off_stats2 = 2 * M;
+    ws->off_stats3 = 4 * M;
+    ws->stats = 4 * M + 2 * G * oc;
+    ws->out = Po * oc;
+    ws->dZ = Po * M;
+    ws->dEh = P * M;
+    ws->off_dgate = 0;
+    ws->off_dpooled = N * M;
+    ws->off_dgl = 2 * N * M;
+    ws->off_dhpre = 3 * N * M;
+    ws->off_cb1 = 3 * N * M + ((N * SE + 3) & ~(uint64_t)3);
+    ws->bsmall = ws->off_cb1 + 4 * M;
+    ws->off_red3 = 0;
+    ws->off_red2 = 2 * G * oc;
+    ws->off_red1 = 2 * G * oc + 2 * M;
+    ws->red = 2 * G * oc + 4 * M;
+    ws->dx = P * d->ic;
+    return 0;
+}
+
+#define TRY(call)               \
+    do {                        \
+        int _r = (call);        \
+        if (_r != 0) return _r; \
+    } while (0)
+
+extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const float* wmix, float* E, float* D,
+                                 float* Pr, float* fsmall, double* stats, float* out, void* stream) {
+    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !out) return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    TfnasCellWs ws;
+    TRY(tfnas_cell_ws(dp, &ws));
+    hipStream_t s = S(stream);
+    double* stats1 = stats + ws.off_stats1;
+    double* stats2 = stats + ws.off_stats2;
+    double* stats3 = stats + ws.off_stats3;
+    float* pooled = fsmall + ws.off_pooled;
+    float* gate = fsmall + ws.off_gate;
+    float* hpre = fsmall + ws.off_hpre;
+    HIP_TRY(hipMemsetAsync(stats, 0, ws.stats * sizeof(double), s));
+    TRY(launch_expand_fwd(d, x, E, stats1, s));           // 1x1 expand (all groups) + BN1 statistics
+    TRY(launch_dw_fwd(d, E, stats1, D, stats2, s));       // BN1+act fused load, depthwise, BN2 statistics
+    TRY(launch_se_pool(d, D, stats2, pooled, s));         // SE squeeze (SE groups only)
+    TRY(launch_se_fc_fwd(d, pooled, hpre, gate, s));      // SE excite
+    TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
+    TRY(launch_mix_fwd(d, Pr, stats3, wmix, x, out, s));  // sum_g w_g BN3(.) + residual
+    return 0;
+}
+
+extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const float* wmix, const float* E,
+                                 const float* D, const float* Pr, const float* fsmall, const double* stats,
+                                 const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* dx,
+                                 float* dwmix, void* stream) {
+    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !dx)
+        return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    TfnasCellWs ws;
+    TRY(tfnas_cell_ws(dp, &ws));
+    hipStream_t s = S(stream);
+    const double* stats1 = stats + ws.off_stats1;
+    const double* stats2 = stats + ws.off_stats2;
+    const double* stats3 = stats + ws.off_stats3;
+    const float* pooled = fsmall + ws.off_pooled;
+    const float* gate = fsmall + ws.off_gate;
+    const float* hpre = fsmall + ws.off_hpre;
+    float* dgate = bsmall + ws.off_dgate;
+    float* dpooled = bsmall + ws.off_dpooled;
+    float* dgl = bsmall + ws.off_dgl;
+    float* dhpre = bsmall + ws.off_dhpre;
+    float* cb1 = bsmall + ws.off_cb1;
+    double* red3 = red + ws.off_red3;
+    double* red2 = red + ws.off_red2;
+    double* red1 = red + ws.off_red1;
+
+    HIP_TRY(hipMemsetAsync(red, 0, ws.red * sizeof(double), s));
+    if (d.need_wgrad) {
+        for (int g = 0; g < d.G; ++g) {
+            const TfnasGroup& gr = d.g[g];
+            if (!gr.g_expand || !gr.g_dw || !gr.g_proj) return TFNAS_ENULL;
+            HIP_TRY(hipMemsetAsync(gr.g_expand, 0, sizeof(float) * (size_t)gr.mc * d.ic, s));
+            HIP_TRY(hipMemsetAsync(gr.g_dw, 0, sizeof(float) * (size_t)gr.mc * gr.k * gr.k, s));
+            HIP_TRY(hipMemsetAsync(gr.g_proj, 0, sizeof(float) * (size_t)gr.mc * d.oc, s));
+            if (gr.se > 0 && (!gr.g_se_r || !gr.gb_se_r || !gr.g_se_e || !gr.gb_se_e)) return TFNAS_ENULL;
+        }
+    }
+    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, red3, s));           // BN3 backward sums (+ d wmix)
+    if (dwmix) TRY(launch_mix_dw(d, red3, dwmix, s));
+    TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
+    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, s));
+    TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
+    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
+    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgl, dhpre, hpre, pooled, s));
+    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, s));     // dZ <- d dhat ; BN2 backward sums
+    TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, s));   // depthwise dgrad + BN1 bwd sums
+    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, s));
+    TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
+    TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, s));       // dx = de W_expand (+ residual)
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, s));
+    return 0;
+}
+
+extern "C" int tfnas_arch_fwd(int ncell, const float* const* log_alpha, const float* e, const float* lat, float T,
+                              float* w, float* cell_lat, void* stream) {
+    if (ncell < 1 || ncell > TFNAS_MAX_CELLS) return TFNAS_ERANGE;
+    if (!log_alpha || !e || !w) return TFNAS_ENULL;
+    return launch_arch_fwd(ncell, log_alpha, e, lat, T, w, cell_lat, S(stream));
+}
+
+extern "C" int tfnas_arch_bwd(int ncell, const float* w, const float* lat, const float* dw, const float* dcell_lat,
+                              float T, float* const* dlog_alpha, void* stream) {
+    if (ncell < 1 || ncell > TFNAS_MAX_CELLS) return TFNAS_ERANGE;
+    if (!w || !dlog_alpha) return TFNAS_ENULL;
+    return launch_arch_bwd(ncell, w, lat, dw, dcell_lat, T, dlog_alpha, S(stream));
+}
+
+extern "C" int tfnas_arch_sample(int ncell, const float* const* log_alpha, const uint8_t* mask, const float* e,
+                                 float T, int mode, int32_t* pos_out, void* stream) {
+    if (ncell < 1 || ncell > TFNAS_MAX_CELLS) return TFNAS_ERANGE;
+    if (!log_alpha || !mask || !pos_out || (mode == 0 && !e)) return TFNAS_ENULL;
+    if (mode < 0 || mode > 2) return TFNAS_EINVAL;
+    return launch_arch_sample(ncell, log_alpha, mask, e, T, mode, pos_out, S(stream));
+}
+
+extern "C" int tfnas_sink_fwd(int K, const float* betas, const float* const* res, const float* cell_lat,
+                              uint64_t count, float* out, float* out_lat, float* bw_out, void* stream) {
+    if (K < 1 || K > TFNAS_MAX_SINK) return TFNAS_ERANGE;
+    if (!betas || !res || !out || !bw_out) return TFNAS_ENULL;
+    if (count & 3) return TFNAS_EINVAL;
+    return launch_sink_fwd(K, betas, res, cell_lat, count, out, out_lat, bw_out, S(stream));
+}
+
+extern "C" int tfnas_sink_bwd(int K, const float* bw, const float* const* res, const float* cell_lat,
+                              const float* dout, const float* dlat, uint64_t count, float* const* dres,
+                              float* dbetas, float* dcell_lat, double* dot_scratch, void* stream) {
+    if (K < 1 || K > TFNAS_MAX_SINK) return TFNAS_ERANGE;
+    if (!bw || !res || !dout || !dres || !dot_scratch) return TFNAS_ENULL;
+    if (count & 3) return TFNAS_EINVAL;
+    return launch_sink_bwd(K, bw, res, cell_lat, dout, dlat, count, dres, dbetas, dcell_lat, dot_scratch, S(stream));
+}

@@ -1,0 +1,189 @@
+// Block-level fp32 GEMM core for gfx950: 128 x (16*NT) output tile per 256-thread workgroup,
+// v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain; 157 TF/s peak = fp32 vector rate), operands
+// staged through LDS in K-major layout so that every MFMA operand fetch is a conflict-free ds_read_b32.
+//
+//   As[k][m]  (leading dim LDA = 144: 144 % 32 == 16 -> lanes 0-15 (k) and 16-31 (k+1) hit disjoint banks)
+//   Bs[k][n]  (leading dim LDB chosen the same way)
+//
+// Operand tiles are produced by *loader functors* so each kernel can fuse its element-wise prologue
+// (BatchNorm normalise, activation, SE gate, BatchNorm backward) into the global->LDS staging:
+//   AK  = true : A source is K-contiguous  : fa(chunk, row,  kl) -> A(row, kl..kl+3),  row<128, kl in {0,4,8,12}
+//   AK  = false: A source is M-contiguous  : fa(chunk, kl,   m ) -> A(m..m+3, kl),     kl<16,  m in {0,4,..,124}
+//   BKC = true : B source is K-contiguous  : fb(chunk, n,    kl) -> B(kl..kl+3, n),    n<BN
+//   BKC = false: B source is N-contiguous  : fb(chunk, kl,   n ) -> B(kl, n..n+3),     n in {0,4,..,BN-4}
+// One K-chunk = 16; global loads of chunk c+1 are issued before the MFMAs of chunk c (register prefetch),
+// LDS is double-buffered, one __syncthreads() per chunk.
+//
+// Accumulator layout (16x16x4 C/D map): acc[i][j][r] = C(wrow + 16*i + 4*(lane>>4) + r, 16*j + (lane&15)),
+// wrow = 32 * wave.
+#pragma once
+#include "tfnas_dev.h"
+
+template <int NT>
+struct GT {
+    static constexpr int BM = 128, BK = 16, BN = 16 * NT;
+    static constexpr int LDA = BM + 16;
+    static constexpr int LDB = (BN % 32 == 16) ? BN : BN + 16;
+    static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    static constexpr int LDS_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+    static constexpr int B_ITEMS = BN * 4;                 // float4 items of one B tile
+    static constexpr int B_ITERS = (B_ITEMS + 255) / 256;
+};
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[2][NT]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+}
+
+template <int NT, bool AK, bool BKC, class FA, class FB>
+__device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4 (&acc)[2][NT], float* lds) {
+    using T = GT<NT>;
+    const int tid = threadIdx.x, lane = tid & 63, wrow = (tid >> 6) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    f32x4 ra[2], rb[T::B_ITERS];
+
+#define TFNAS_GLOAD(c)                                                                      \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
+            const int idx = tid + 256 * i;                                                  \
+            ra[i] = AK ? fa((c), idx >> 2, (idx & 3) * 4) : fa((c), idx >> 5, (idx & 31) * 4); \
+        }                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            const int idx = tid + 256 * i;                                                  \
+            if (idx < T::B_ITEMS)                                                           \
+                rb[i] = BKC ? fb((c), idx >> 2, (idx & 3) * 4)                              \
+                            : fb((c), idx / (T::BN / 4), (idx % (T::BN / 4)) * 4);          \
+        }                                                                                   \
+    }
+#define TFNAS_SSTORE(As, Bs)                                                                \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
+            const int idx = tid + 256 * i;                                                  \
+            if (AK) {                                                                       \
+                const int row = idx >> 2, kl = (idx & 3) * 4;                               \
+                (As)[(kl + 0) * T::LDA + row] = ra[i].x;                                    \
+                (As)[(kl + 1) * T::LDA + row] = ra[i].y;                                    \
+                (As)[(kl + 2) * T::LDA + row] = ra[i].z;                                    \
+                (As)[(kl + 3) * T::LDA + row] = ra[i].w;                                    \
+            } else {                                                                        \
+                st4(&(As)[(idx >> 5) * T::LDA + (idx & 31) * 4], ra[i]);                    \
+            }                                                                               \
+        }                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            const int idx = tid + 256 * i;                                                  \
+            if (idx < T::B_ITEMS) {                                                         \
+                if (BKC) {                                                                  \
+                    const int n = idx >> 2, kl = (idx & 3) * 4;                             \
+                    (Bs)[(kl + 0) * T::LDB + n] = rb[i].x;                                  \
+                    (Bs)[(kl + 1) * T::LDB + n] = rb[i].y;                                  \
+                    (Bs)[(kl + 2) * T::LDB + n] = rb[i].z;                                  \
+                    (Bs)[(kl + 3) * T::LDB + n] = rb[i].w;                                  \
+                } else {                                                                    \
+                    st4(&(Bs)[(idx / (T::BN / 4)) * T::LDB + (idx % (T::BN / 4)) * 4], rb[i]); \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+    }
+
+    float* As0 = lds;
+    float* As1 = lds + T::A_FLOATS;
+    float* Bs0 = lds + 2 * T::A_FLOATS;
+    float* Bs1 = Bs0 + T::B_FLOATS;
+
+    if (nchunks > 0) {
+        TFNAS_GLOAD(0);
+        TFNAS_SSTORE(As0, Bs0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* As = (c & 1) ? As1 : As0;
+        const float* Bs = (c & 1) ? Bs1 : Bs0;
+        const bool more = (c + 1 < nchunks);
+        if (more) TFNAS_GLOAD(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            const float a0 = As[k * T::LDA + wrow + lr];
+            const float a1 = As[k * T::LDA + wrow + 16 + lr];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float b = Bs[k * T::LDB + 16 * j + lr];
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            if (c & 1) { TFNAS_SSTORE(As0, Bs0); } else { TFNAS_SSTORE(As1, Bs1); }
+        }
+        __syncthreads();
+    }
+#undef TFNAS_GLOAD
+#undef TFNAS_SSTORE
+}
+
+// Per-column sums of the accumulator tile (rows outside the problem contribute exact zeros because the
+// loaders zero-fill them).  Adds this tile's column sum / sum of squares into per-lane running totals.
+template <int NT>
+__device__ __forceinline__ void acc_colstats(const f32x4 (&acc)[2][NT], float (&s)[NT], float (&q)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 v = acc[i][j];
+            s[j] += (v.x + v.y) + (v.z + v.w);
+            q[j] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+}
+
+// Block-reduce the per-lane column totals (over the 4 lane groups and 4 waves) and add them to the
+// double-precision (sum, sumsq) accumulators of columns [col0, col0+BN) that are < col_lim.
+template <int NT>
+__device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], float* lds, double* stats,
+                                               int col0, int col_lim) {
+    using T = GT<NT>;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        s[j] += __shfl_xor(s[j], 16, 64);
+        s[j] += __shfl_xor(s[j], 32, 64);
+        q[j] += __shfl_xor(q[j], 16, 64);
+        q[j] += __shfl_xor(q[j], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            lds[(w * 2 + 0) * T::BN + 16 * j + lr] = s[j];
+            lds[(w * 2 + 1) * T::BN + 16 * j + lr] = q[j];
+        }
+    }
+    __syncthreads();
+    if (tid < T::BN && col0 + tid < col_lim) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            ss += lds[(ww * 2 + 0) * T::BN + tid];
+            qq += lds[(ww * 2 + 1) * T::BN + tid];
+        }
+        atomic_add_f64(&stats[2 * (size_t)(col0 + tid) + 0], (double)ss);
+        atomic_add_f64(&stats[2 * (size_t)(col0 + tid) + 1], (double)qq);
+    }
+    __syncthreads();
+}
+
+// NT choice for an N extent: minimise padded columns, prefer the wider tile on ties.
+static inline int pick_nt(int n, const int* cands, int ncand) {
+    int best = cands[0];
+    long best_pad = -1;
+    for (int i = 0; i < ncand; ++i) {
+        const int bn = 16 * cands[i];
+        const long pad = (long)((n + bn - 1) / bn) * bn;
+        if (best_pad < 0 || pad < best_pad || (pad == best_pad && cands[i] > best)) {
+            best_pad = pad;
+            best = cands[i];
+        }
+    }
+    return best;
+}

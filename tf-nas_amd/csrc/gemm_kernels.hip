@@ -1,0 +1,537 @@
+// 1x1-convolution (pointwise) kernels of the MBConv candidates as fp32 MFMA GEMMs with fused
+// BatchNorm / activation / SE prologues and BatchNorm-statistics epilogues.
+//
+// Reference arithmetic: MBInvertedResBlock.forward, models/layers.py:539-561
+//   expand  = inverted_bottleneck.conv (layers.py:463-478)   project = point_linear.conv (layers.py:528-534)
+// and the autograd backward of those convolutions + BatchNorm2d(affine=False, batch stats).
+#include "gemm_core.h"
+#include "kernels.h"
+
+// ============================================================================ expand forward
+// E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
+// epilogue: per-channel (sum, sumsq) of E -> stats1 (BN1 batch statistics)
+template <int NT>
+__global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
+                                                    float* __restrict__ E, double* __restrict__ stats1) {
+    using T = GT<NT>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    int ty = blockIdx.y, g = 0;
+    for (; g < d.G - 1; ++g) {
+        const int t = (d.g[g].mcp + T::BN - 1) / T::BN;
+        if (ty < t) break;
+        ty -= t;
+    }
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const float* __restrict__ w = d.g[g].w_expand;
+    const int n0 = ty * T::BN;
+    const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
+    const int nrt = (P + 127) >> 7, nchunks = (ic + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+
+    float cs[NT], cq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+
+    for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+        f32x4 acc[2][NT];
+        acc_zero<NT>(acc);
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int p = rt * 128 + row, k = c * 16 + kl;
+            return (p < P && k < ic) ? ld4(x + (size_t)p * ic + k) : zero4();
+        };
+        auto fb = [&](int c, int n, int kl) -> f32x4 {
+            const int col = n0 + n, k = c * 16 + kl;
+            return (col < mc && k < ic) ? ld4(w + (size_t)col * ic + k) : zero4();
+        };
+        gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
+                if (p < P) {
+                    float* dst = E + (size_t)p * M + off + n0 + lr;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (n0 + 16 * j + lr < mcp) dst[16 * j] = acc[i][j][r];
+                }
+            }
+        acc_colstats<NT>(acc, cs, cq);
+    }
+    flush_colstats<NT>(cs, cq, lds, stats1 + 2 * (size_t)off, n0, mc);
+}
+
+// ============================================================================ project forward
+// Pr[g][p][o] = sum_c z_g[p][c] * w_proj_g[o][c],   z = act(BN2(D)) * gate   (fused into the A load)
+// epilogue: stats3[g][o] (BN3 batch statistics)
+template <int NT, int ACT>
+__global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
+                                                     const float* __restrict__ gate,
+                                                     const double* __restrict__ stats2, float* __restrict__ Pr,
+                                                     double* __restrict__ stats3) {
+    using T = GT<NT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.z;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0, w_al = (mc & 3) == 0;
+    const float* __restrict__ w = d.g[g].w_proj;
+    const int n0 = blockIdx.y * T::BN;
+    const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
+    const int nrt = (Po + 127) >> 7, nchunks = (mcp + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+
+    float2* cst = reinterpret_cast<float2*>(lds + T::LDS_FLOATS);
+    for (int c = tid; c < ((mcp + 15) & ~15); c += 256)
+        cst[c] = (c < mc) ? bn_consts(stats2 + 2 * (size_t)(off + c), 1.0 / (double)Po, d.eps) : make_float2(0.f, 0.f);
+    __syncthreads();
+
+    float cs[NT], cq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+
+    for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+        f32x4 acc[2][NT];
+        acc_zero<NT>(acc);
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int p = rt * 128 + row, k = c * 16 + kl;
+            if (p >= Po || k >= mcp) return zero4();
+            f32x4 v = ld4(D + (size_t)p * M + off + k);
+            const float2 c0 = cst[k], c1 = cst[k + 1], c2 = cst[k + 2], c3 = cst[k + 3];
+            v.x = act_f<ACT>((v.x - c0.x) * c0.y);
+            v.y = act_f<ACT>((v.y - c1.x) * c1.y);
+            v.z = act_f<ACT>((v.z - c2.x) * c2.y);
+            v.w = act_f<ACT>((v.w - c3.x) * c3.y);
+            if (has_se) v *= ld4(gate + (size_t)(p / HW) * M + off + k);
+            return v;
+        };
+        auto fb = [&](int c, int n, int kl) -> f32x4 {
+            const int o = n0 + n, k = c * 16 + kl;
+            return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, w_al) : zero4();
+        };
+        gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
+                if (p < Po) {
+                    float* dst = Pr + ((size_t)g * Po + p) * oc + n0 + lr;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (n0 + 16 * j + lr < oc) dst[16 * j] = acc[i][j][r];
+                }
+            }
+        acc_colstats<NT>(acc, cs, cq);
+    }
+    flush_colstats<NT>(cs, cq, lds, stats3 + 2 * (size_t)g * oc, n0, oc);
+}
+
+// ---------------------------------------------------------------------------- BN3-backward operand
+// dP_g[p][o] = A3[o] * (dOut[p][o] - B3[o] - phat[p][o]*C3[o]),  phat = (Pr - mean3)*rstd3,
+// A3 = wmix_g * rstd3, B3 = S1/Po, C3 = S2/Po  (S1,S2 = red3 sums of dOut and dOut*phat)
+struct Bn3Tab {  // 5 floats per output channel, in LDS
+    float *mean, *rstd, *a3, *b3, *c3;
+};
+__device__ __forceinline__ Bn3Tab bn3_tab_fill(float* base, int ocp, const TfnasCellDesc& d, int g,
+                                               const double* stats3, const double* red3, const float* wmix) {
+    Bn3Tab t{base, base + ocp, base + 2 * ocp, base + 3 * ocp, base + 4 * ocp};
+    const int Po = d.N * d.Ho * d.Wo;
+    const double inv = 1.0 / (double)Po;
+    const float wg = wmix ? wmix[g] : 1.f;
+    for (int o = threadIdx.x; o < ocp; o += blockDim.x) {
+        if (o < d.oc) {
+            const float2 c = bn_consts(stats3 + 2 * ((size_t)g * d.oc + o), inv, d.eps);
+            t.mean[o] = c.x;
+            t.rstd[o] = c.y;
+            t.a3[o] = wg * c.y;
+            t.b3[o] = (float)(red3[2 * ((size_t)g * d.oc + o) + 0] * inv);
+            t.c3[o] = (float)(red3[2 * ((size_t)g * d.oc + o) + 1] * inv);
+        } else {
+            t.mean[o] = t.rstd[o] = t.a3[o] = t.b3[o] = t.c3[o] = 0.f;
+        }
+    }
+    return t;
+}
+__device__ __forceinline__ f32x4 bn3_dp(const Bn3Tab& t, int o, f32x4 dout, f32x4 pr) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float ph = (pr[j] - t.mean[o + j]) * t.rstd[o + j];
+        r[j] = t.a3[o + j] * (dout[j] - t.b3[o + j] - ph * t.c3[o + j]);
+    }
+    return r;
+}
+
+// ============================================================================ project dgrad
+// dZ[p][off_g + c] = sum_o dP_g[p][o] * w_proj_g[o][c]
+template <int NT>
+__global__ __launch_bounds__(256) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
+                                                       const float* __restrict__ Pr,
+                                                       const double* __restrict__ stats3,
+                                                       const double* __restrict__ red3,
+                                                       const float* __restrict__ wmix, float* __restrict__ dZ) {
+    using T = GT<NT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int ty = blockIdx.y, g = 0;
+    for (; g < d.G - 1; ++g) {
+        const int t = (d.g[g].mcp + T::BN - 1) / T::BN;
+        if (ty < t) break;
+        ty -= t;
+    }
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool w_al = (mc & 3) == 0;
+    const float* __restrict__ w = d.g[g].w_proj;
+    const int n0 = ty * T::BN;
+    const int Po = d.N * d.Ho * d.Wo, oc = d.oc, M = d.M;
+    const int ocp = (oc + 15) & ~15;
+    const int nrt = (Po + 127) >> 7, nchunks = ocp >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+
+    const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
+    __syncthreads();
+
+    for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+        f32x4 acc[2][NT];
+        acc_zero<NT>(acc);
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int p = rt * 128 + row, o = c * 16 + kl;
+            if (p >= Po || o >= oc) return zero4();
+            return bn3_dp(tab, o, ld4(dout + (size_t)p * oc + o), ld4(Pr + ((size_t)g * Po + p) * oc + o));
+        };
+        auto fb = [&](int c, int kl, int n) -> f32x4 {
+            const int o = c * 16 + kl;
+            return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, w_al) : zero4();
+        };
+        gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
+                if (p < Po) {
+                    float* dst = dZ + (size_t)p * M + off + n0 + lr;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (n0 + 16 * j + lr < mcp) dst[16 * j] = acc[i][j][r];
+                }
+            }
+    }
+}
+
+// ============================================================================ project wgrad (TN, split-K)
+// g_proj_g[o][c] += sum_p dP_g[p][o] * z_g[p][c]       (atomics over the K-splits; buffer pre-zeroed)
+// tile: M side = mid channels c (128), N side = output channels o (16*NT)
+template <int NT, int ACT>
+__global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const float* __restrict__ dout,
+                                                       const float* __restrict__ Pr, const float* __restrict__ D,
+                                                       const float* __restrict__ gate,
+                                                       const double* __restrict__ stats2,
+                                                       const double* __restrict__ stats3,
+                                                       const double* __restrict__ red3,
+                                                       const float* __restrict__ wmix, int rows_per_split,
+                                                       int ntiles_o) {
+    using T = GT<NT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.z / ntiles_o, n0 = (blockIdx.z % ntiles_o) * T::BN;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0;
+    float* __restrict__ gw = d.g[g].g_proj;
+    const int m0 = blockIdx.y * 128;
+    if (m0 >= mcp) return;
+    const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
+    const int ocp = (oc + 15) & ~15;
+    const int r0 = blockIdx.x * rows_per_split, r1 = min(Po, r0 + rows_per_split);
+    const int nchunks = (r1 - r0 + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+
+    const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
+    // this thread always stages the same 4 mid channels: keep their BN2 constants in registers
+    const int mch = m0 + (tid & 31) * 4;
+    float2 c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c2[j] = (mch + j < mc) ? bn_consts(stats2 + 2 * (size_t)(off + mch + j), 1.0 / (double)Po, d.eps)
+                               : make_float2(0.f, 0.f);
+    __syncthreads();
+
+    f32x4 acc[2][NT];
+    acc_zero<NT>(acc);
+    auto fa = [&](int c, int kl, int m) -> f32x4 {
+        const int p = r0 + c * 16 + kl, ch = m0 + m;
+        if (p >= r1 || ch >= mcp) return zero4();
+        f32x4 v = ld4(D + (size_t)p * M + off + ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
+        if (has_se) v *= ld4(gate + (size_t)(p / HW) * M + off + ch);
+        return v;
+    };
+    auto fb = [&](int c, int kl, int n) -> f32x4 {
+        const int p = r0 + c * 16 + kl, o = n0 + n;
+        if (p >= r1 || o >= oc) return zero4();
+        return bn3_dp(tab, o, ld4(dout + (size_t)p * oc + o), ld4(Pr + ((size_t)g * Po + p) * oc + o));
+    };
+    gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = m0 + wrow + 16 * i + 4 * lq + r;
+            if (ch < mc) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int o = n0 + 16 * j + lr;
+                    if (o < oc) atomic_add_f32(gw + (size_t)o * mc + ch, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------- BN1-backward operand
+// de[p][c] = rstd1 * (deh - T1/P - ehat*T2/P), ehat = (E-mean1)*rstd1, deh = dA1*act'(ehat) (stored by the
+// depthwise-backward kernel);  cb1[c] = (mean1, rstd1, T1/P, T2/P)
+__device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = cb[j];
+        const float eh = (e[j] - t.x) * t.y;
+        r[j] = t.y * (deh[j] - t.z - eh * t.w);
+    }
+    return r;
+}
+
+// ============================================================================ expand dgrad
+// dx[p][c] = sum_g sum_m de[p][off_g+m] * w_expand_g[m][c]  (+ sumw * dout[p][c] for residual cells)
+template <int NT>
+__global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+                                                      const float* __restrict__ E, const float* __restrict__ cb1,
+                                                      const float* __restrict__ dout,
+                                                      const float* __restrict__ wmix, float* __restrict__ dx) {
+    using T = GT<NT>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    const int n0 = blockIdx.y * T::BN;
+    const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
+    const int nrt = (P + 127) >> 7;
+    int nchunks = 0;
+    for (int g = 0; g < d.G; ++g) nchunks += (d.g[g].mcp + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    float sumw = 1.f;
+    if (wmix) {
+        sumw = 0.f;
+        for (int g = 0; g < d.G; ++g) sumw += wmix[g];
+    }
+    const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
+
+    for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+        f32x4 acc[2][NT];
+        acc_zero<NT>(acc);
+        auto locate = [&](int c, int& g, int& k0) {
+            g = 0;
+            for (; g < d.G - 1; ++g) {
+                const int t = (d.g[g].mcp + 15) >> 4;
+                if (c < t) break;
+                c -= t;
+            }
+            k0 = c * 16;
+        };
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            int g, k0;
+            locate(c, g, k0);
+            const int p = rt * 128 + row, k = k0 + kl;
+            if (p >= P || k >= d.g[g].mcp) return zero4();
+            const size_t col = (size_t)d.g[g].off + k;
+            return bn1_de(cb + col, ld4(dEh + (size_t)p * M + col), ld4(E + (size_t)p * M + col));
+        };
+        auto fb = [&](int c, int kl, int n) -> f32x4 {
+            int g, k0;
+            locate(c, g, k0);
+            const int k = k0 + kl;
+            return (k < d.g[g].mc && n0 + n < ic) ? ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
+        };
+        gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
+                if (p < P) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int c = n0 + 16 * j + lr;
+                        if (c < ic) {
+                            float v = acc[i][j][r];
+                            if (d.has_res) v += sumw * dout[(size_t)p * d.oc + c];
+                            dx[(size_t)p * ic + c] = v;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// ============================================================================ expand wgrad (TN, split-K)
+// g_expand_g[m][c] += sum_p de[p][off_g+m] * x[p][c]
+template <int NT>
+__global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+                                                      const float* __restrict__ E, const float* __restrict__ cb1,
+                                                      const float* __restrict__ x, int rows_per_split) {
+    using T = GT<NT>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    int ty = blockIdx.y, g = 0;
+    for (; g < d.G - 1; ++g) {
+        const int t = (d.g[g].mcp + 127) >> 7;
+        if (ty < t) break;
+        ty -= t;
+    }
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    float* __restrict__ gw = d.g[g].g_expand;
+    const int m0 = ty * 128, n0 = blockIdx.z * T::BN;
+    const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
+    const int r0 = blockIdx.x * rows_per_split, r1 = min(P, r0 + rows_per_split);
+    const int nchunks = (r1 - r0 + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+
+    const int mch = m0 + (tid & 31) * 4;
+    f32x4 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        cb[j] = (mch + j < mcp) ? reinterpret_cast<const f32x4*>(cb1)[off + mch + j] : zero4();
+
+    f32x4 acc[2][NT];
+    acc_zero<NT>(acc);
+    auto fa = [&](int c, int kl, int m) -> f32x4 {
+        const int p = r0 + c * 16 + kl, ch = m0 + m;
+        if (p >= r1 || ch >= mcp) return zero4();
+        const size_t col = (size_t)off + ch;
+        return bn1_de(cb, ld4(dEh + (size_t)p * M + col), ld4(E + (size_t)p * M + col));
+    };
+    auto fb = [&](int c, int kl, int n) -> f32x4 {
+        const int p = r0 + c * 16 + kl, cc = n0 + n;
+        return (p < r1 && cc < ic) ? ld4(x + (size_t)p * ic + cc) : zero4();
+    };
+    gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = m0 + wrow + 16 * i + 4 * lq + r;
+            if (ch < mc) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int cc = n0 + 16 * j + lr;
+                    if (cc < ic) atomic_add_f32(gw + (size_t)ch * ic + cc, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+// ============================================================================ host launchers
+static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channel counts (ic / oc)
+static const int kNtWide[] = {4};                   // N extents that are mid-channel groups
+
+#define DISPATCH_NT(nt, ...)                                  \
+    switch (nt) {                                             \
+        case 1: { constexpr int NT = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NT = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NT = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int NT = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int NT = 5; __VA_ARGS__; } break; \
+        case 7: { constexpr int NT = 7; __VA_ARGS__; } break; \
+        default: return TFNAS_EINVAL;                         \
+    }
+#define DISPATCH_ACT(act, ...)                                                        \
+    if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; } \
+    else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
+
+static int row_blocks(int rows, int other_blocks) {
+    const int nrt = cdiv(rows, 128);
+    int want = cdiv(4096, other_blocks > 0 ? other_blocks : 1);   // ~16 workgroups per CU in total
+    if (want < 1) want = 1;
+    return nrt < want ? nrt : want;
+}
+
+int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, hipStream_t s) {
+    constexpr int NT = 4;
+    int tiles = 0;
+    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles), tiles);
+    hipLaunchKernelGGL(k_expand_fwd<NT>, grid, dim3(256), 0, s, d, x, E, stats1);
+    return (int)hipGetLastError();
+}
+
+int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
+                       float* Pr, double* stats3, hipStream_t s) {
+    const int nt = pick_nt(d.oc, kNtSmall, 6);
+    int mcp_max = 0;
+    for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
+    const int tiles = cdiv(d.oc, 16 * nt);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G), tiles, d.G);
+    DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
+        const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
+        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, stats3);
+    }))
+    return (int)hipGetLastError();
+}
+
+int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
+                         const double* red3, const float* wmix, float* dZ, hipStream_t s) {
+    constexpr int NT = 4;
+    int tiles = 0;
+    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles), tiles);
+    const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
+    hipLaunchKernelGGL(k_project_dgrad<NT>, grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
+    return (int)hipGetLastError();
+}
+
+static int pick_rows_per_split(int rows, int out_tiles) {
+    // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split
+    int splits = cdiv(1024, out_tiles > 0 ? out_tiles : 1);
+    int rps = cdiv(rows, splits > 0 ? splits : 1);
+    if (rps < 256) rps = 256;
+    return ((rps + 15) / 16) * 16;
+}
+
+int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
+                         const float* gate, const double* stats2, const double* stats3, const double* red3,
+                         const float* wmix, hipStream_t s) {
+    const int nt = pick_nt(d.oc, kNtSmall, 6);
+    const int Po = d.N * d.Ho * d.Wo;
+    int mcp_max = 0;
+    for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
+    const int mtiles = cdiv(mcp_max, 128), ntiles = cdiv(d.oc, 16 * nt);
+    const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G);
+    dim3 grid(cdiv(Po, rps), mtiles, ntiles * d.G);
+    DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
+        const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
+        hipLaunchKernelGGL((k_project_wgrad<NT, ACT>), grid, dim3(256), shm, s, d, dout, Pr, D, gate, stats2,
+                           stats3, red3, wmix, rps, ntiles);
+    }))
+    return (int)hipGetLastError();
+}
+
+int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+                        const float* dout, const float* wmix, float* dx, hipStream_t s) {
+    const int nt = pick_nt(d.ic, kNtSmall, 6);
+    const int tiles = cdiv(d.ic, 16 * nt);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles), tiles);
+    DISPATCH_NT(nt, {
+        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, dout, wmix, dx);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+                        const float* x, hipStream_t s) {
+    const int nt = pick_nt(d.ic, kNtSmall, 6);
+    const int P = d.N * d.H * d.W;
+    int mtiles = 0;
+    for (int g = 0; g < d.G; ++g) mtiles += cdiv(d.g[g].mcp, 128);
+    const int ntiles = cdiv(d.ic, 16 * nt);
+    const int rps = pick_rows_per_split(P, mtiles * ntiles);
+    dim3 grid(cdiv(P, rps), mtiles, ntiles);
+    DISPATCH_NT(nt, {
+        hipLaunchKernelGGL(k_expand_wgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps);
+    })
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,59 @@
+// Internal launcher prototypes (one per kernel family); the extern "C" surface is in capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tfnas_hip.h"
+
+// gemm_kernels.hip
+int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, hipStream_t s);
+int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
+                       float* Pr, double* stats3, hipStream_t s);
+int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
+                         const double* red3, const float* wmix, float* dZ, hipStream_t s);
+int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
+                         const float* gate, const double* stats2, const double* stats3, const double* red3,
+                         const float* wmix, hipStream_t s);
+int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+                        const float* dout, const float* wmix, float* dx, hipStream_t s);
+int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+                        const float* x, hipStream_t s);
+
+// dwconv_kernels.hip
+int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
+                  hipStream_t s);
+int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+                       const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
+                       hipStream_t s);
+int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+                    const double* red2, const float* E, const double* stats1, hipStream_t s);
+
+// pointwise_kernels.hip (SE, BN2 backward statistics, mixing epilogue, BN constant tables)
+int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2, float* pooled, hipStream_t s);
+int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s);
+int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
+                   const float* x, float* out, hipStream_t s);
+int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
+                         double* red3, hipStream_t s);
+int launch_mix_dw(const TfnasCellDesc& d, const double* red3, float* dwmix, hipStream_t s);
+int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
+                         float* dgate, hipStream_t s);
+int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
+                     float* dgl, float* dhpre, float* dpooled, hipStream_t s);
+int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre, const float* hpre,
+                    const float* pooled, hipStream_t s);
+int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
+                   const float* dpooled, double* red2, hipStream_t s);
+int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,
+                      hipStream_t s);
+
+// arch_kernels.hip
+int launch_arch_fwd(int ncell, const float* const* la, const float* e, const float* lat, float T, float* w,
+                    float* cell_lat, hipStream_t s);
+int launch_arch_bwd(int ncell, const float* w, const float* lat, const float* dw, const float* dcl, float T,
+                    float* const* dla, hipStream_t s);
+int launch_arch_sample(int ncell, const float* const* la, const uint8_t* mask, const float* e, float T, int mode,
+                       int32_t* pos, hipStream_t s);
+int launch_sink_fwd(int K, const float* betas, const float* const* res, const float* cell_lat, uint64_t count,
+                    float* out, float* out_lat, float* bw, hipStream_t s);
+int launch_sink_bwd(int K, const float* bw, const float* const* res, const float* cell_lat, const float* dout,
+                    const float* dlat, uint64_t count, float* const* dres, float* dbetas, float* dcell_lat,
+                    double* dots, hipStream_t s);

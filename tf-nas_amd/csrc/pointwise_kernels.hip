@@ -1,0 +1,494 @@
+// Bandwidth-bound kernels of the MixedOP cell that are not convolutions:
+//   squeeze-excite (pool, two tiny FCs, their backward)      models/layers.py:509-526, forward :548-550
+//   softmax(alpha)-weighted mixing of the candidates + BN3    models/model_search.py:89, layers.py:528-534
+//   BatchNorm backward statistics passes (autograd of BatchNorm2d(affine=False) with batch statistics)
+#include "tfnas_dev.h"
+#include "kernels.h"
+
+// sum v over the threads of the block that share `col` (rows pr = 0..RP-1); result valid where pr == 0
+__device__ __forceinline__ f32x4 reduce_rows(f32x4 v, f32x4* buf, int pr, int col, int RP, int TQ, bool active) {
+    __syncthreads();
+    if (active) buf[pr * TQ + col] = v;
+    __syncthreads();
+    f32x4 r = zero4();
+    if (active && pr == 0)
+        for (int q = 0; q < RP; ++q) r += buf[q * TQ + col];
+    return r;
+}
+
+// locate the `idx`-th chunk of CH channels among SE groups (se_only) or all groups
+__device__ __forceinline__ bool chunk_locate(const TfnasCellDesc& d, int cy, int CH, bool se_only, int& g, int& c0) {
+    for (g = 0; g < d.G; ++g) {
+        if (se_only && d.g[g].se == 0) continue;
+        const int t = (d.g[g].mcp + CH - 1) / CH;
+        if (cy < t) {
+            c0 = cy * CH;
+            return true;
+        }
+        cy -= t;
+    }
+    return false;
+}
+static int chunk_count(const TfnasCellDesc& d, int CH, bool se_only) {
+    int t = 0;
+    for (int g = 0; g < d.G; ++g)
+        if (!se_only || d.g[g].se > 0) t += cdiv(d.g[g].mcp, CH);
+    return t;
+}
+__device__ __forceinline__ int se_group(const TfnasCellDesc& d, int idx) {
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0 && idx-- == 0) return g;
+    return -1;
+}
+static int se_group_count(const TfnasCellDesc& d) {
+    int t = 0;
+    for (int g = 0; g < d.G; ++g) t += d.g[g].se > 0;
+    return t;
+}
+
+// ============================================================================ SE squeeze (global average pool)
+// MODE 0: pooled[n][c] = mean_hw act(BN2(D))            (forward)
+// MODE 1: dgate [n][c] = sum_hw  dZ * act(BN2(D))       (backward of the gate multiply)
+template <int ACT, int MODE>
+__global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* __restrict__ D,
+                                                 const double* __restrict__ stats2, const float* __restrict__ dZ,
+                                                 float* __restrict__ outp) {
+    __shared__ f32x4 buf[256];
+    int g, c0;
+    if (!chunk_locate(d, blockIdx.y, 64, true, g, c0)) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = c0 + 4 * cq;
+    const bool active = ch < mcp;
+    float2 c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c2[j] = (active && ch + j < mc) ? bn_consts(stats2 + 2 * (size_t)(off + ch + j), 1.0 / ((double)d.N * HW), d.eps)
+                                        : make_float2(0.f, 0.f);
+    f32x4 acc = zero4();
+    if (active) {
+        for (int hw = rl; hw < HW; hw += 16) {
+            const size_t a = ((size_t)n * HW + hw) * M + off + ch;
+            f32x4 v = ld4(D + a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
+            if (MODE == 1) v *= ld4(dZ + a);
+            acc += v;
+        }
+    }
+    acc = reduce_rows(acc, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) {
+        if (MODE == 0) acc *= splat4(1.f / (float)HW);
+        st4(outp + (size_t)n * M + off + ch, acc);
+    }
+}
+
+// ============================================================================ SE excite (two 1x1 convs on [N, mc])
+// hpre = W_r pooled + b_r ; h = act(hpre) ; gate = sigmoid(W_e h + b_e)
+template <int ACT>
+__global__ __launch_bounds__(256) void k_se_fc_fwd(TfnasCellDesc d, const float* __restrict__ pooled,
+                                                   float* __restrict__ hpre, float* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = se_group(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const float* __restrict__ wr = d.g[g].w_se_r;
+    const float* __restrict__ br = d.g[g].b_se_r;
+    const float* __restrict__ we = d.g[g].w_se_e;
+    const float* __restrict__ be = d.g[g].b_se_e;
+    const int n = blockIdx.x, M = d.M, SE = d.SE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* pl = lds;
+    float* hs = lds + mcp;
+    for (int c = tid; c < mc; c += 256) pl[c] = pooled[(size_t)n * M + off + c];
+    __syncthreads();
+    for (int j = wv; j < se; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < mc; c += 64) s += wr[(size_t)j * mc + c] * pl[c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float hp = s + br[j];
+            hpre[(size_t)n * SE + so + j] = hp;
+            hs[j] = act_f<ACT>(hp);
+        }
+    }
+    __syncthreads();
+    for (int c = wv; c < mcp; c += 4) {
+        float s = 0.f;
+        if (c < mc)
+            for (int j = lane; j < se; j += 64) s += we[(size_t)c * se + j] * hs[j];
+        s = wave_sum(s);
+        if (lane == 0) gate[(size_t)n * M + off + c] = (c < mc) ? sigmoid_f(s + be[c]) : 0.f;
+    }
+}
+
+// backward of the excite FCs for one sample:
+//   dgl = dgate * g (1-g) ; dh = W_e^T dgl ; dhpre = dh * act'(hpre) ; dpooled = W_r^T dhpre
+template <int ACT>
+__global__ __launch_bounds__(256) void k_se_fc_bwd(TfnasCellDesc d, const float* __restrict__ dgate,
+                                                   const float* __restrict__ gate, const float* __restrict__ hpre,
+                                                   float* __restrict__ dgl, float* __restrict__ dhpre,
+                                                   float* __restrict__ dpooled) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = se_group(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const float* __restrict__ wr = d.g[g].w_se_r;
+    const float* __restrict__ we = d.g[g].w_se_e;
+    const int n = blockIdx.x, M = d.M, SE = d.SE, tid = threadIdx.x;
+    float* dgs = lds;
+    float* dhs = lds + mcp;
+    for (int c = tid; c < mcp; c += 256) {
+        float v = 0.f;
+        if (c < mc) {
+            const float gt = gate[(size_t)n * M + off + c];
+            v = dgate[(size_t)n * M + off + c] * gt * (1.f - gt);
+        }
+        dgs[c] = v;
+        dgl[(size_t)n * M + off + c] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < se; j += 256) {
+        float s = 0.f;
+        for (int c = 0; c < mc; ++c) s += we[(size_t)c * se + j] * dgs[c];
+        const float v = s * act_d<ACT>(hpre[(size_t)n * SE + so + j]);
+        dhs[j] = v;
+        dhpre[(size_t)n * SE + so + j] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < mcp; c += 256) {
+        float s = 0.f;
+        if (c < mc)
+            for (int j = 0; j < se; ++j) s += wr[(size_t)j * mc + c] * dhs[j];
+        dpooled[(size_t)n * M + off + c] = s;
+    }
+}
+
+// weight gradients of the excite FCs (sums over the batch), one element per thread
+template <int ACT>
+__global__ __launch_bounds__(256) void k_se_wgrad(TfnasCellDesc d, const float* __restrict__ dgl,
+                                                  const float* __restrict__ dhpre, const float* __restrict__ hpre,
+                                                  const float* __restrict__ pooled) {
+    const int g = se_group(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int N = d.N, M = d.M, SE = d.SE;
+    const long total = 2L * mc * se + mc + se;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        float s = 0.f;
+        if (idx < (long)mc * se) {                       // g_se_e[c][j] = sum_n dgl[n][c] * h[n][j]
+            const int c = (int)(idx / se), j = (int)(idx % se);
+            for (int n = 0; n < N; ++n)
+                s += dgl[(size_t)n * M + off + c] * act_f<ACT>(hpre[(size_t)n * SE + so + j]);
+            d.g[g].g_se_e[idx] = s;
+        } else if (idx < 2L * mc * se) {                 // g_se_r[j][c] = sum_n dhpre[n][j] * pooled[n][c]
+            const long i2 = idx - (long)mc * se;
+            const int j = (int)(i2 / mc), c = (int)(i2 % mc);
+            for (int n = 0; n < N; ++n) s += dhpre[(size_t)n * SE + so + j] * pooled[(size_t)n * M + off + c];
+            d.g[g].g_se_r[i2] = s;
+        } else if (idx < 2L * mc * se + mc) {            // gb_se_e[c]
+            const int c = (int)(idx - 2L * mc * se);
+            for (int n = 0; n < N; ++n) s += dgl[(size_t)n * M + off + c];
+            d.g[g].gb_se_e[c] = s;
+        } else {                                         // gb_se_r[j]
+            const int j = (int)(idx - 2L * mc * se - mc);
+            for (int n = 0; n < N; ++n) s += dhpre[(size_t)n * SE + so + j];
+            d.g[g].gb_se_r[j] = s;
+        }
+    }
+}
+
+// ============================================================================ mixing epilogue (forward)
+// out[p][o] = sum_g wmix[g] * BN3(Pr[g])[p][o]  (+ (sum_g wmix[g]) * x[p][o] for residual cells)
+__global__ __launch_bounds__(256) void k_mix_fwd(TfnasCellDesc d, const float* __restrict__ Pr,
+                                                 const double* __restrict__ stats3, const float* __restrict__ wmix,
+                                                 const float* __restrict__ x, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float2* tab = reinterpret_cast<float2*>(lds);   // [G*oc] (mean3, rstd3*w)
+    const int oc = d.oc, G = d.G, OQ = oc >> 2;
+    const int Po = d.N * d.Ho * d.Wo;
+    float sumw = 0.f;
+    for (int g = 0; g < G; ++g) sumw += wmix ? wmix[g] : 1.f;
+    for (int i = threadIdx.x; i < G * oc; i += 256) {
+        const float2 c = bn_consts(stats3 + 2 * (size_t)i, 1.0 / (double)Po, d.eps);
+        tab[i] = make_float2(c.x, c.y * (wmix ? wmix[i / oc] : 1.f));
+    }
+    __syncthreads();
+    const size_t total = (size_t)Po * OQ;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t p = idx / OQ;
+        const int o = (int)(idx % OQ) * 4;
+        f32x4 v = zero4();
+        for (int g = 0; g < G; ++g) {
+            const f32x4 pr = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = tab[g * oc + o + j];
+                v[j] += (pr[j] - t.x) * t.y;
+            }
+        }
+        if (d.has_res) v += splat4(sumw) * ld4(x + p * d.ic + o);
+        st4(out + p * oc + o, v);
+    }
+}
+
+// ============================================================================ mixing epilogue (backward sums)
+// red3[g][o] = ( S1 = sum_p dout[p][o] ,  S2 = sum_p dout[p][o] * phat_g[p][o] )
+__global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const float* __restrict__ dout,
+                                                       const float* __restrict__ Pr,
+                                                       const double* __restrict__ stats3,
+                                                       double* __restrict__ red3, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int oc = d.oc, G = d.G, TQ = oc >> 2, RP = 256 / TQ;
+    const int Po = d.N * d.Ho * d.Wo;
+    float2* tab = reinterpret_cast<float2*>(lds);                    // [G*oc] (mean3, rstd3)
+    f32x4* buf = reinterpret_cast<f32x4*>(lds + 2 * G * oc);         // [256]
+    for (int i = threadIdx.x; i < G * oc; i += 256) tab[i] = bn_consts(stats3 + 2 * (size_t)i, 1.0 / (double)Po, d.eps);
+    __syncthreads();
+    const int tid = threadIdx.x, oq = tid % TQ, pr = tid / TQ, o = 4 * oq;
+    const bool active = pr < RP;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(Po, p0 + rows_per_block);
+    f32x4 s1 = zero4(), s2[TFNAS_MAX_GROUPS];
+#pragma unroll
+    for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) s2[g] = zero4();
+    if (active) {
+        for (int p = p0 + pr; p < p1; p += RP) {
+            const f32x4 dv = ld4(dout + (size_t)p * oc + o);
+            s1 += dv;
+#pragma unroll
+            for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
+                if (g < G) {
+                    const f32x4 pv = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float2 t = tab[g * oc + o + j];
+                        s2[g][j] += dv[j] * ((pv[j] - t.x) * t.y);
+                    }
+                }
+            }
+        }
+    }
+    s1 = reduce_rows(s1, buf, pr, oq, RP, TQ, active);
+#pragma unroll
+    for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
+        if (g < G) {
+            const f32x4 r = reduce_rows(s2[g], buf, pr, oq, RP, TQ, active);
+            if (active && pr == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    atomic_add_f64(red3 + 2 * ((size_t)g * oc + o + j) + 0, (double)s1[j]);
+                    atomic_add_f64(red3 + 2 * ((size_t)g * oc + o + j) + 1, (double)r[j]);
+                }
+            }
+        }
+    }
+}
+
+// dwmix[g] = <dout, phat_g> = sum_o S2[g][o]   (the residual's <dout,x> term is the same for every g and is
+// annihilated by the softmax Jacobian, so it is omitted)
+__global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, float* __restrict__ dwmix) {
+    const int g = threadIdx.x;
+    if (g < d.G) {
+        double s = 0.0;
+        for (int o = 0; o < d.oc; ++o) s += red3[2 * ((size_t)g * d.oc + o) + 1];
+        dwmix[g] = (float)s;
+    }
+}
+
+// ============================================================================ BN2 backward, pass 1
+// in place: dZ <- ddh = (dZ*gate + dpooled/HW) * act'(dhat) ;  red2[c] = (sum ddh, sum ddh*dhat)
+template <int ACT>
+__global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, float* __restrict__ dZ, const float* __restrict__ D,
+                                                 const double* __restrict__ stats2, const float* __restrict__ gate,
+                                                 const float* __restrict__ dpooled, double* __restrict__ red2,
+                                                 int rows_per_block) {
+    __shared__ f32x4 buf[256];
+    int g, c0;
+    if (!chunk_locate(d, blockIdx.y, 64, false, g, c0)) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0;
+    const int HW = d.Ho * d.Wo, Po = d.N * HW, M = d.M;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = c0 + 4 * cq;
+    const bool active = ch < mcp;
+    float2 c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c2[j] = (active && ch + j < mc) ? bn_consts(stats2 + 2 * (size_t)(off + ch + j), 1.0 / (double)Po, d.eps)
+                                        : make_float2(0.f, 0.f);
+    const float inv_hw = 1.f / (float)HW;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(Po, p0 + rows_per_block);
+    f32x4 r1 = zero4(), r2 = zero4();
+    if (active) {
+        for (int p = p0 + rl; p < p1; p += 16) {
+            const size_t a = (size_t)p * M + off + ch;
+            f32x4 da = ld4(dZ + a);
+            const f32x4 dv = ld4(D + a);
+            if (has_se) {
+                const size_t b = (size_t)(p / HW) * M + off + ch;
+                da = da * ld4(gate + b) + ld4(dpooled + b) * splat4(inv_hw);
+            }
+            f32x4 ddh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dh = (dv[j] - c2[j].x) * c2[j].y;
+                ddh[j] = da[j] * act_d<ACT>(dh);
+                r1[j] += ddh[j];
+                r2[j] += ddh[j] * dh;
+            }
+            st4(dZ + a, ddh);
+        }
+    }
+    r1 = reduce_rows(r1, buf, rl, cq, 16, 16, active);
+    r2 = reduce_rows(r2, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ch + j < mc) {
+                atomic_add_f64(red2 + 2 * (size_t)(off + ch + j) + 0, (double)r1[j]);
+                atomic_add_f64(red2 + 2 * (size_t)(off + ch + j) + 1, (double)r2[j]);
+            }
+    }
+}
+
+// cb1[c] = (mean1, rstd1, T1/P, T2/P) for the expand dgrad / wgrad operand loaders
+__global__ void k_bn1_consts(TfnasCellDesc d, const double* __restrict__ stats1, const double* __restrict__ red1,
+                             float* __restrict__ cb1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.M) return;
+    const double inv = 1.0 / ((double)d.N * d.H * d.W);
+    const float2 m = bn_consts(stats1 + 2 * (size_t)c, inv, d.eps);
+    f32x4 t;
+    t.x = m.x;
+    t.y = m.y;
+    t.z = (float)(red1[2 * (size_t)c + 0] * inv);
+    t.w = (float)(red1[2 * (size_t)c + 1] * inv);
+    // pad channels (never accumulated) have zero sums -> mean 0; force rstd 0 so they stay exactly 0
+    bool is_pad = true;
+    for (int g = 0; g < d.G; ++g)
+        if (c >= d.g[g].off && c < d.g[g].off + d.g[g].mc) is_pad = false;
+    if (is_pad) t = zero4();
+    reinterpret_cast<f32x4*>(cb1)[c] = t;
+}
+
+// ============================================================================ host launchers
+#define ACT_DISPATCH(act, ...)                                                          \
+    if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; }   \
+    else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
+
+int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2, float* pooled, hipStream_t s) {
+    const int chunks = chunk_count(d, 64, true);
+    if (!chunks) return 0;
+    dim3 grid(d.N, chunks);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_se_pool<ACT, 0>), grid, dim3(256), 0, s, d, D, stats2, (const float*)nullptr, pooled);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
+                         float* dgate, hipStream_t s) {
+    const int chunks = chunk_count(d, 64, true);
+    if (!chunks) return 0;
+    dim3 grid(d.N, chunks);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_se_pool<ACT, 1>), grid, dim3(256), 0, s, d, D, stats2, dZ, dgate);
+    })
+    return (int)hipGetLastError();
+}
+
+static size_t se_fc_shm(const TfnasCellDesc& d) {
+    int m = 0;
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0 && d.g[g].mcp + d.g[g].se > m) m = d.g[g].mcp + d.g[g].se;
+    return (size_t)(m + 4) * sizeof(float);
+}
+
+int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s) {
+    const int ng = se_group_count(d);
+    if (!ng) return 0;
+    dim3 grid(d.N, ng);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_se_fc_fwd<ACT>), grid, dim3(256), se_fc_shm(d), s, d, pooled, hpre, gate);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
+                     float* dgl, float* dhpre, float* dpooled, hipStream_t s) {
+    const int ng = se_group_count(d);
+    if (!ng) return 0;
+    dim3 grid(d.N, ng);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_se_fc_bwd<ACT>), grid, dim3(256), se_fc_shm(d), s, d, dgate, gate, hpre, dgl, dhpre,
+                           dpooled);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre, const float* hpre,
+                    const float* pooled, hipStream_t s) {
+    const int ng = se_group_count(d);
+    if (!ng) return 0;
+    long mx = 0;
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0) {
+            const long t = 2L * d.g[g].mc * d.g[g].se + d.g[g].mc + d.g[g].se;
+            mx = t > mx ? t : mx;
+        }
+    int bx = (int)((mx + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    dim3 grid(bx, ng);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_se_wgrad<ACT>), grid, dim3(256), 0, s, d, dgl, dhpre, hpre, pooled);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
+                   const float* x, float* out, hipStream_t s) {
+    const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4);
+    size_t blocks = cdiv64(total, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const size_t shm = (size_t)2 * d.G * d.oc * sizeof(float);
+    hipLaunchKernelGGL(k_mix_fwd, dim3((unsigned)blocks), dim3(256), shm, s, d, Pr, stats3, wmix, x, out);
+    return (int)hipGetLastError();
+}
+
+int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
+                         double* red3, hipStream_t s) {
+    const int Po = d.N * d.Ho * d.Wo;
+    int rpb = cdiv(Po, 1024);
+    const int RP = 256 / (d.oc / 4);
+    if (rpb < 8 * RP) rpb = 8 * RP;
+    const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
+    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(cdiv(Po, rpb)), dim3(256), shm, s, d, dout, Pr, stats3, red3, rpb);
+    return (int)hipGetLastError();
+}
+
+int launch_mix_dw(const TfnasCellDesc& d, const double* red3, float* dwmix, hipStream_t s) {
+    hipLaunchKernelGGL(k_mix_dw, dim3(1), dim3(64), 0, s, d, red3, dwmix);
+    return (int)hipGetLastError();
+}
+
+int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
+                   const float* dpooled, double* red2, hipStream_t s) {
+    const int Po = d.N * d.Ho * d.Wo;
+    const int chunks = chunk_count(d, 64, false);
+    int want = cdiv(2048, chunks);
+    int rpb = cdiv(Po, want < 1 ? 1 : want);
+    if (rpb < 64) rpb = 64;
+    dim3 grid(cdiv(Po, rpb), chunks);
+    ACT_DISPATCH(d.act, {
+        hipLaunchKernelGGL((k_bn2_bwd<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, gate, dpooled, red2, rpb);
+    })
+    return (int)hipGetLastError();
+}
+
+int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_bn1_consts, dim3(cdiv(d.M, 256)), dim3(256), 0, s, d, stats1, red1, cb1);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,82 @@
+// Device-side helpers shared by all gfx950 kernels of the TF-NAS hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tfnas_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TFNAS_THREADS 256
+
+#define HIP_TRY(expr)                         \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ----------------------------------------------------------------------------- activations
+// reference: Swish = x * sigmoid(x) (models/layers.py:26-35), ReLU (layers.py:470-471)
+template <int ACT>
+__device__ __forceinline__ float act_f(float x) {
+    if (ACT == TFNAS_ACT_RELU) return fmaxf(x, 0.f);
+    return x / (1.f + __expf(-x));
+}
+// derivative w.r.t. the pre-activation x
+template <int ACT>
+__device__ __forceinline__ float act_d(float x) {
+    if (ACT == TFNAS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    float s = 1.f / (1.f + __expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+template <int ACT>
+__device__ __forceinline__ f32x4 act_f4(f32x4 v) {
+    f32x4 r;
+    r.x = act_f<ACT>(v.x); r.y = act_f<ACT>(v.y); r.z = act_f<ACT>(v.z); r.w = act_f<ACT>(v.w);
+    return r;
+}
+template <int ACT>
+__device__ __forceinline__ f32x4 act_d4(f32x4 v) {
+    f32x4 r;
+    r.x = act_d<ACT>(v.x); r.y = act_d<ACT>(v.y); r.z = act_d<ACT>(v.z); r.w = act_d<ACT>(v.w);
+    return r;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ----------------------------------------------------------------------------- batch-norm constants
+// stats layout: [channel][2] doubles = (sum, sum of squares) over `cnt` elements.
+// BN of the search net: (x-mean)/sqrt(var_biased+eps), no affine (layers.py:469,498,533).
+__device__ __forceinline__ float2 bn_consts(const double* st, double inv_cnt, float eps) {
+    double m = st[0] * inv_cnt;
+    double v = st[1] * inv_cnt - m * m;
+    if (v < 0.0) v = 0.0;
+    return make_float2((float)m, (float)(1.0 / sqrt(v + (double)eps)));
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ f32x4 splat4(float a) { f32x4 z = {a, a, a, a}; return z; }
+
+// load 4 consecutive floats that may be unaligned / partially out of range [0, lim)
+__device__ __forceinline__ f32x4 ld4_guard(const float* base, int idx, int lim, bool aligned) {
+    f32x4 r = zero4();
+    if (aligned && idx + 3 < lim) return ld4(base + idx);
+    if (idx < lim) r.x = base[idx];
+    if (idx + 1 < lim) r.y = base[idx + 1];
+    if (idx + 2 < lim) r.z = base[idx + 2];
+    if (idx + 3 < lim) r.w = base[idx + 3];
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// atomic accumulate into double / float device memory (ordinary coarse-grained allocations)
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

@@ -1,0 +1,95 @@
+"""ctypes binding of libtfnas_hip.so (C ABI: include/tfnas_hip.h).
+
+The shared library is built in-tree by ``tf-nas_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is
+NO fallback: if the library is missing or an entry point returns non-zero, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtfnas_hip.so')
+
+MAX_GROUPS, MAX_SINK, MAX_CELLS = 8, 4, 32
+ACT = {'relu': 0, 'swish': 1}
+
+_W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e')
+_G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
+
+
+class TfnasGroup(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('mc', 'k', 'se', 'mcp', 'off', 'se_off', 'pad0', 'pad1')]
+                + [(n, C.c_void_p) for n in _W_FIELDS] + [(n, C.c_void_p) for n in _G_FIELDS])
+
+
+class TfnasCellDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
+                                          'Ho', 'Wo', 'M', 'SE')]
+                + [('eps', C.c_float), ('pad0', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+
+
+class TfnasCellWs(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        'E', 'D', 'Pr', 'fsmall', 'off_pooled', 'off_gate', 'off_hpre', 'stats', 'off_stats1', 'off_stats2',
+        'off_stats3', 'out', 'dZ', 'dEh', 'bsmall', 'off_dgate', 'off_dpooled', 'off_dgl', 'off_dhpre', 'off_cb1',
+        'red', 'off_red3', 'off_red2', 'off_red1', 'dx')]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    'tfnas_abi_version': (C.c_int, []),
+    'tfnas_sizeof': (C.c_uint64, [C.c_int]),
+    'tfnas_cell_plan': (C.c_int, [C.POINTER(TfnasCellDesc)]),
+    'tfnas_cell_ws': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasCellWs)]),
+    'tfnas_mixedop_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 9),
+    'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 15),
+    'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
+    'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
+    'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
+    'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),
+    'tfnas_sink_bwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, _P, _P, C.c_uint64, C.POINTER(_P), _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises RuntimeError when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'tfnas_amd: HIP extension %s is missing -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C tf-nas_amd/csrc`). There is no CPU/PyTorch fallback for the MixedOP hot path.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)        # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if l.tfnas_abi_version() != 1:
+            raise RuntimeError('tfnas_amd: ABI version mismatch')
+        for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs)):
+            if l.tfnas_sizeof(which) != C.sizeof(st):
+                raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('tfnas_hip: %s failed with code %d (%s)' % (
+            what, rc, 'invalid argument' if rc < 0 else 'hipError_t'))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def exported_names():
+    return list(_PROTOS)

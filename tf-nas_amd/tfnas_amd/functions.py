@@ -1,0 +1,228 @@
+"""torch.autograd.Functions that hand the MixedOP / arch-parameter / sink arithmetic to the HIP library.
+
+PyTorch is used here for what the task calls plumbing: device memory (the caller-allocated buffers of the
+C ABI are torch tensors), the current HIP stream, and the autograd tape.  No arithmetic of the hot path is
+done with torch ops in this file.
+
+Layout: public tensors are logically NCHW (reference API) but must be ``channels_last`` in memory, i.e.
+NHWC in HBM; ``_nhwc`` makes that view (zero-copy when the producer already wrote channels_last, which all
+functions here do).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import TfnasCellDesc, TfnasCellWs, ptr, ptr_array, check
+
+BN_EPS = 1e-5
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _nhwc(x):
+    """[N,C,H,W] logical -> contiguous [N,H,W,C] view (copies only if x is not channels_last)."""
+    v = x.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('tfnas_amd: %s must live on the GPU -- the MixedOP hot path has no CPU implementation '
+                           '(the CPU restatement is oracle/tfnas_oracle.py, test infrastructure only)' % what)
+    if t.dtype != torch.float32:
+        raise RuntimeError('tfnas_amd: %s must be float32' % what)
+
+
+class CellPlan:
+    """Host-side description of one MixedOP launch: geometry + which candidate blocks take part."""
+
+    def __init__(self, ic, oc, stride, act, blocks):
+        self.ic, self.oc, self.stride, self.act = ic, oc, stride, act
+        self.blocks = list(blocks)                     # MBInvertedResBlock modules (parameter containers)
+        self.has_res = int(ic == oc and stride == 1)
+        self._desc_cache = {}
+
+    def params(self):
+        ps = []
+        for b in self.blocks:
+            ps.extend(b.hip_params())
+        return ps
+
+    def desc(self, N, H, W):
+        key = (N, H, W)
+        hit = self._desc_cache.get(key)
+        if hit is None:
+            d = TfnasCellDesc()
+            d.N, d.H, d.W, d.ic, d.oc, d.stride = N, H, W, self.ic, self.oc, self.stride
+            d.act, d.has_res, d.G, d.need_wgrad, d.eps = _lib.ACT[self.act], self.has_res, len(self.blocks), 0, BN_EPS
+            for g, b in enumerate(self.blocks):
+                d.g[g].mc, d.g[g].k, d.g[g].se = b.mid_channels, b.kernel_size, b.se_channels
+            check(_lib.lib().tfnas_cell_plan(C.byref(d)), 'tfnas_cell_plan')
+            ws = TfnasCellWs()
+            check(_lib.lib().tfnas_cell_ws(C.byref(d), C.byref(ws)), 'tfnas_cell_ws')
+            hit = (d, ws)
+            self._desc_cache[key] = hit
+        return hit
+
+    def bind(self, d, params, grads=None):
+        """Write current weight (and gradient) pointers into the descriptor."""
+        i = 0
+        for g, b in enumerate(self.blocks):
+            n = 7 if b.se_channels > 0 else 3
+            for j, f in enumerate(_lib._W_FIELDS[:n]):
+                setattr(d.g[g], f, params[i + j].data_ptr())
+            if grads is not None:
+                for j, f in enumerate(_lib._G_FIELDS[:n]):
+                    setattr(d.g[g], f, grads[i + j].data_ptr())
+            i += n
+        d.need_wgrad = int(grads is not None)
+
+
+class MixedOpFn(torch.autograd.Function):
+    """out = sum_g wmix[g] * MBConv_g(x)   (soft mode)   or   MBConv_idx(x)   (sampled mode, wmix=None).
+
+    Replaces MixedOP.forward's arithmetic (models/model_search.py:84-85 and :89) and its autograd backward."""
+
+    @staticmethod
+    def forward(ctx, plan, x, wmix, *params):
+        _require_cuda(x, 'MixedOP input')
+        xh = _nhwc(x)
+        N, H, W, _ = xh.shape
+        d, ws = plan.desc(N, H, W)
+        for p in params:
+            _require_cuda(p, 'MBConv weight')
+            if not p.is_contiguous():
+                raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
+        plan.bind(d, params)
+        dev = x.device
+        E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+        D = torch.empty(ws.D, device=dev, dtype=torch.float32)
+        Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
+        fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
+        stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
+        out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
+        if wmix is not None:
+            wmix = wmix.contiguous()
+        check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                           ptr(stats), ptr(out), _stream()), 'tfnas_mixedop_fwd')
+        ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
+        ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
+        ctx.debug = None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xh, wmix, E, D, Pr, fsmall, stats, *params = ctx.saved_tensors
+        plan = ctx.plan
+        N, H, W = ctx.shape
+        d, ws = plan.desc(N, H, W)
+        dev = xh.device
+        need_w = any(ctx.needs_input_grad[3:])
+        grads = [torch.empty_like(p) for p in params] if need_w else None
+        plan.bind(d, params, grads)
+        douth = _nhwc(dout)
+        dZ = torch.empty(ws.dZ, device=dev, dtype=torch.float32)
+        dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
+        bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
+        red = torch.empty(ws.red, device=dev, dtype=torch.float64)
+        dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
+        dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
+        check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                           ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
+                                           ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+        d.need_wgrad = 0
+        if MixedOpFn.debug_sink is not None:
+            MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
+        out = [None, dx.permute(0, 3, 1, 2), dwmix]
+        out.extend(grads if need_w else [None] * len(params))
+        return tuple(out)
+
+
+MixedOpFn.debug_sink = None      # tests set this to a list to capture backward scratch tensors
+
+
+class ArchFn(torch.autograd.Function):
+    """(w[ncell,8], cell_lat[ncell]) = gumbel-softmax over every cell's log_alphas + expected cell latency.
+
+    Replaces F.gumbel_softmax(self.log_alphas, self.T) and sum(w*lat) of MixedOP.forward
+    (models/model_search.py:87,90) for all cells of the network in one launch."""
+
+    @staticmethod
+    def forward(ctx, e, lat, T, *log_alphas):
+        ncell = len(log_alphas)
+        for a in log_alphas:
+            _require_cuda(a, 'log_alphas')
+        dev = e.device
+        e = e.contiguous().float()
+        lat = lat.contiguous().float()
+        w = torch.empty((ncell, 8), device=dev, dtype=torch.float32)
+        cl = torch.empty((ncell,), device=dev, dtype=torch.float32)
+        check(_lib.lib().tfnas_arch_fwd(ncell, ptr_array(log_alphas), ptr(e), ptr(lat), float(T), ptr(w), ptr(cl),
+                                        _stream()), 'tfnas_arch_fwd')
+        ctx.save_for_backward(w, lat)
+        ctx.T, ctx.ncell = float(T), ncell
+        return w, cl
+
+    @staticmethod
+    def backward(ctx, dw, dcl):
+        w, lat = ctx.saved_tensors
+        dla = [torch.empty(8, device=w.device, dtype=torch.float32) for _ in range(ctx.ncell)]
+        dw = None if dw is None else dw.contiguous()
+        dcl = None if dcl is None else dcl.contiguous()
+        check(_lib.lib().tfnas_arch_bwd(ctx.ncell, ptr(w), ptr(lat), ptr(dw), ptr(dcl), ctx.T, ptr_array(dla),
+                                        _stream()), 'tfnas_arch_bwd')
+        return (None, None, None) + tuple(dla)
+
+
+def arch_sample(log_alphas, masks, e, T, mode):
+    """Positions (among switched-on candidates) chosen by mode 'gumbel'(0) / 'min_alphas'(1) / 'max_alphas'(2)
+    for all cells; one device->host copy for the whole network (the reference does one .item() per cell,
+    models/model_search.py:63,67,71,75)."""
+    ncell = len(log_alphas)
+    dev = log_alphas[0].device
+    mask_t = torch.tensor(masks, dtype=torch.uint8).to(dev)
+    pos = torch.empty(ncell, device=dev, dtype=torch.int32)
+    e = None if e is None else e.contiguous().float()
+    check(_lib.lib().tfnas_arch_sample(ncell, ptr_array(log_alphas), ptr(mask_t), ptr(e), float(T), int(mode),
+                                       ptr(pos), _stream()), 'tfnas_arch_sample')
+    return pos.cpu().tolist()
+
+
+class SinkFn(torch.autograd.Function):
+    """(out, out_lat) = softmax(betas)-weighted sum of the K depth outputs of a stage and of their cumulative
+    latencies.  Replaces MixedStage.forward's tail (models/model_search.py:202-204)."""
+
+    @staticmethod
+    def forward(ctx, betas, cell_lat, *res):
+        K = len(res)
+        _require_cuda(betas, 'betas')
+        rh = [_nhwc(r) for r in res]
+        dev = betas.device
+        out = torch.empty_like(rh[0])
+        out_lat = torch.zeros((), device=dev, dtype=torch.float32)
+        bw = torch.empty(K, device=dev, dtype=torch.float32)
+        cl = None if cell_lat is None else cell_lat.contiguous()
+        check(_lib.lib().tfnas_sink_fwd(K, ptr(betas), ptr_array(rh), ptr(cl), rh[0].numel(), ptr(out), ptr(out_lat),
+                                        ptr(bw), _stream()), 'tfnas_sink_fwd')
+        ctx.save_for_backward(bw, cl, *rh)
+        ctx.K = K
+        return out.permute(0, 3, 1, 2), out_lat
+
+    @staticmethod
+    def backward(ctx, dout, dlat):
+        bw, cl, *rh = ctx.saved_tensors
+        K = ctx.K
+        dev = bw.device
+        douth = _nhwc(dout)
+        dres = [torch.empty_like(r) for r in rh]
+        dbetas = torch.empty(K, device=dev, dtype=torch.float32)
+        dcl = None if cl is None else torch.empty(K, device=dev, dtype=torch.float32)
+        dots = torch.empty(_lib.MAX_SINK, device=dev, dtype=torch.float64)
+        dlat = None if dlat is None else dlat.contiguous()
+        check(_lib.lib().tfnas_sink_bwd(K, ptr(bw), ptr_array(rh), ptr(cl), ptr(douth), ptr(dlat), rh[0].numel(),
+                                        ptr_array(dres), ptr(dbetas), ptr(dcl), ptr(dots), _stream()),
+              'tfnas_sink_bwd')
+        return (dbetas, dcl) + tuple(r.permute(0, 3, 1, 2) for r in dres)

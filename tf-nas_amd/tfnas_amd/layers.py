@@ -1,0 +1,149 @@
+"""Layer library with the reference's class / attribute / parameter names (models/layers.py).
+
+Only what the search hot path touches is provided:
+  MBInvertedResBlock  (models/layers.py:431-561)  -- parameter container with the reference's sub-module names
+                      (``inverted_bottleneck.conv``, ``depth_conv.conv``, ``squeeze_excite.conv_reduce/conv_expand``,
+                      ``point_linear.conv``) so that train_search.py:164-193's ``exec`` weight slicing and the
+                      state_dict keys (:244-258) keep working.  Its arithmetic runs in the HIP library.
+  ConvLayer / LinearLayer (models/layers.py:190-271, :322-428) -- stems and head; SURVEY.md section 8(a) a9 leaves
+                      these 1.6 % of the MACs to stock PyTorch-ROCm ops.
+  Swish               (models/layers.py:26-35)
+BatchNorm of the search net has no affine and no running statistics (layers.py:101-103,469,498,533): it is
+a pure function of the batch and therefore has no module/state here.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functions import CellPlan, MixedOpFn, BN_EPS
+
+
+class Swish(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        return x.mul_(x.sigmoid()) if self.inplace else x * x.sigmoid()
+
+
+def _bn(x):
+    return F.batch_norm(x, None, None, None, None, True, 0.0, BN_EPS)
+
+
+def _act(x, act_func):
+    if act_func == 'relu':
+        return F.relu(x)
+    if act_func == 'swish':
+        return x * torch.sigmoid(x)
+    if act_func is None:
+        return x
+    raise ValueError('unsupported act_func: %s' % act_func)
+
+
+def get_same_padding(kernel_size):
+    assert kernel_size % 2 > 0, 'kernel size should be odd number'
+    return kernel_size // 2
+
+
+class ConvLayer(nn.Module):
+    """conv -> BN(batch stats, no affine) -> act; stems/head only (stock PyTorch-ROCm ops)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, affine=False, act_func='relu'):
+        super().__init__()
+        if affine:
+            raise NotImplementedError('search-net layers are affine=False (model_search.py:219-275)')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.act_func = kernel_size, stride, act_func
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, get_same_padding(kernel_size),
+                              bias=False)
+
+    @property
+    def name(self):
+        return 'ConvLayer'
+
+    def forward(self, x):
+        return _act(_bn(self.conv(x)), self.act_func)
+
+
+class LinearLayer(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.linear = nn.Linear(in_features, out_features, bias)
+
+    @property
+    def name(self):
+        return 'LinearLayer'
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+def _seq(**mods):
+    return nn.Sequential(OrderedDict(mods))
+
+
+class MBInvertedResBlock(nn.Module):
+    """MBConv block: 1x1 expand -> BN -> act -> depthwise kxk -> BN -> act -> [SE] -> 1x1 project -> BN [-> +x].
+
+    With an expand convolution (every search candidate) ``forward`` runs the fused HIP path (sampled mode of
+    ``tfnas_mixedop_fwd``); without one (only ``second_stem``: mid == in) it is a stem and uses torch ops."""
+
+    def __init__(self, in_channels, mid_channels, se_channels, out_channels, kernel_size=3, stride=1,
+                 affine=False, act_func='relu'):
+        super().__init__()
+        if affine:
+            raise NotImplementedError('search-net blocks are affine=False')
+        self.in_channels, self.mid_channels = in_channels, mid_channels
+        self.se_channels, self.out_channels = se_channels, out_channels
+        self.kernel_size, self.stride, self.act_func = kernel_size, stride, act_func
+        self.affine = affine
+        self.drop_connect_rate = 0.0
+        if mid_channels > in_channels:
+            self.inverted_bottleneck = _seq(conv=nn.Conv2d(in_channels, mid_channels, 1, 1, 0, bias=False))
+        else:
+            self.inverted_bottleneck = None
+            self.mid_channels = mid_channels = in_channels
+        self.depth_conv = _seq(conv=nn.Conv2d(mid_channels, mid_channels, kernel_size, stride,
+                                              get_same_padding(kernel_size), groups=mid_channels, bias=False))
+        if se_channels > 0:
+            self.squeeze_excite = _seq(conv_reduce=nn.Conv2d(mid_channels, se_channels, 1, 1, 0, bias=True),
+                                       conv_expand=nn.Conv2d(se_channels, mid_channels, 1, 1, 0, bias=True))
+        else:
+            self.squeeze_excite = None
+            self.se_channels = 0
+        self.point_linear = _seq(conv=nn.Conv2d(mid_channels, out_channels, 1, 1, 0, bias=False))
+        self.has_residual = (in_channels == out_channels) and (stride == 1)
+        self._plan = None
+
+    @property
+    def name(self):
+        return 'MBInvertedResBlock'
+
+    def hip_params(self):
+        """Weights in the order of TfnasGroup's pointer fields."""
+        ps = [self.inverted_bottleneck.conv.weight, self.depth_conv.conv.weight, self.point_linear.conv.weight]
+        if self.squeeze_excite is not None:
+            se = self.squeeze_excite
+            ps += [se.conv_reduce.weight, se.conv_reduce.bias, se.conv_expand.weight, se.conv_expand.bias]
+        return ps
+
+    def _stem_forward(self, x):
+        res = x
+        y = _act(_bn(self.depth_conv.conv(x)), self.act_func)
+        if self.squeeze_excite is not None:
+            s = F.adaptive_avg_pool2d(y, 1)
+            s = self.squeeze_excite.conv_expand(_act(self.squeeze_excite.conv_reduce(s), self.act_func))
+            y = y * torch.sigmoid(s)
+        y = _bn(self.point_linear.conv(y))
+        return y + res if self.has_residual else y
+
+    def forward(self, x):
+        if self.inverted_bottleneck is None:
+            return self._stem_forward(x)
+        if self._plan is None:
+            self._plan = CellPlan(self.in_channels, self.out_channels, self.stride, self.act_func, [self])
+        return MixedOpFn.apply(self._plan, x, None, *self.hip_params())

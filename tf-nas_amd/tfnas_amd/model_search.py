@@ -1,0 +1,305 @@
+"""Supernet for the TF-NAS search -- drop-in for the reference's ``models/model_search.py``.
+
+Same classes, constructor signatures, ``forward(x, sampling, mode)`` signatures, parameter names/order and
+helper methods as the reference (Network :213-365, MixedStage :125-210, MixedOP :32-122); the arithmetic of
+every MixedOP cell, of the Gumbel-softmax over the arch parameters and of the sink-connecting stage mix runs
+in hand-written HIP kernels (libtfnas_hip.so, C ABI in include/tfnas_hip.h).
+
+Differences a caller can see (all optional):
+  * ``forward`` accepts two extra keyword arguments, ``exp_noise`` (Exp(1) draws, [ncell, 8]) and ``rand_pos``
+    (positions for mode 'random'), so tests / data-parallel ranks can inject identical noise.  When omitted,
+    Exp(1) noise is drawn on the device with torch's generator and 'random' uses python's ``random`` exactly
+    like the reference (models/model_search.py:79).
+  * tensors must live on the GPU; there is no CPU path (the oracle in oracle/ is test infrastructure).
+"""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functions import ArchFn, CellPlan, MixedOpFn, SinkFn, arch_sample
+from .layers import ConvLayer, LinearLayer, MBInvertedResBlock
+
+PRIMITIVES = [
+    'MBI_k3_e3', 'MBI_k3_e6', 'MBI_k5_e3', 'MBI_k5_e6',
+    'MBI_k3_e3_se', 'MBI_k3_e6_se', 'MBI_k5_e3_se', 'MBI_k5_e6_se',
+]
+
+# (kernel, SE width as multiple of ic); the e3/e6 ratio only enters through mc_num_dict (model_search.py:19-29)
+_OP_SPEC = {
+    'MBI_k3_e3': (3, 0), 'MBI_k3_e6': (3, 0), 'MBI_k5_e3': (5, 0), 'MBI_k5_e6': (5, 0),
+    'MBI_k3_e3_se': (3, 1), 'MBI_k3_e6_se': (3, 2), 'MBI_k5_e3_se': (5, 1), 'MBI_k5_e6_se': (5, 2),
+}
+
+OPS = {
+    name: (lambda ic, mc, oc, s, aff, act, _k=k, _se=se:
+           MBInvertedResBlock(ic, mc, ic * _se, oc, _k, s, affine=aff, act_func=act))
+    for name, (k, se) in _OP_SPEC.items()
+}
+
+_SAMPLE_MODES = {'gumbel': 0, 'gumbel_2': 0, 'min_alphas': 1, 'max_alphas': 2}
+
+
+class MixedOP(nn.Module):
+    def __init__(self, in_channels, out_channels, stride, affine, act_func, num_ops, mc_num_dict, lat_lookup):
+        super().__init__()
+        self.num_ops = num_ops
+        self.lat_lookup = lat_lookup
+        self.mc_num_dict = mc_num_dict
+        self.in_channels, self.out_channels, self.stride, self.act_func = in_channels, out_channels, stride, act_func
+        self.m_ops = nn.ModuleList()
+        for i in range(num_ops):
+            self.m_ops.append(OPS[PRIMITIVES[i]](in_channels, self.mc_num_dict[i], out_channels, stride, affine,
+                                                 act_func))
+        self._initialize_log_alphas()
+        self.reset_switches()
+        self.T = 1.0
+        self._plans = {}
+        self._lat_cache = {}
+        self._pre = None           # (w_row, cell_lat) or sampled position handed down by Network.forward
+
+    # ---- reference helpers -------------------------------------------------------------------------
+    def fink_ori_idx(self, idx):
+        count = 0
+        for ori_idx in range(len(self.switches)):
+            if self.switches[ori_idx]:
+                count += 1
+                if count == (idx + 1):
+                    break
+        return ori_idx
+
+    def get_lookup_latency(self, size):
+        lats = []
+        for op in self.m_ops:
+            key = '{}_{}_{}_{}_{}_k{}_s{}_{}'.format(op.name, size, op.in_channels, op.se_channels, op.out_channels,
+                                                     op.kernel_size, op.stride, op.act_func)
+            lats.append(self.lat_lookup[key][op.mid_channels])
+        return lats
+
+    def _initialize_log_alphas(self):
+        self.register_parameter('log_alphas', nn.Parameter(F.log_softmax(torch.zeros((self.num_ops,)), dim=-1)))
+
+    def reset_switches(self):
+        self.switches = [True] * self.num_ops
+
+    def set_temperature(self, T):
+        self.T = T
+
+    # ---- HIP plumbing --------------------------------------------------------------------------------
+    def _plan(self, idxs):
+        key = tuple(idxs)
+        p = self._plans.get(key)
+        if p is None:
+            p = CellPlan(self.in_channels, self.out_channels, self.stride, self.act_func,
+                         [self.m_ops[i] for i in idxs])
+            self._plans[key] = p
+        return p
+
+    def lat_tensor(self, size, device):
+        """Looked-up latencies of the 8 candidates as a device tensor (cached per input size / widths)."""
+        key = (size, str(device), tuple(op.mid_channels for op in self.m_ops))
+        t = self._lat_cache.get(key)
+        if t is None:
+            t = torch.tensor(self.get_lookup_latency(size), dtype=torch.float32, device=device)
+            self._lat_cache = {key: t}
+        return t
+
+    def sample_index(self, mode, exp_noise=None, rand_pos=None, pos=None):
+        """Bi-sampling bookkeeping of models/model_search.py:59-81; returns the chosen original op index.
+        ``pos`` is the device-computed position for the gumbel / min / max modes."""
+        nactive = sum(self.switches)
+        if mode in _SAMPLE_MODES:
+            if pos is None:
+                if mode.startswith('gumbel') and exp_noise is None:
+                    exp_noise = torch.empty(8, device=self.log_alphas.device).exponential_()
+                pos = arch_sample([self.log_alphas], [[int(s) for s in self.switches]],
+                                  None if exp_noise is None else exp_noise.reshape(1, -1)[:, :8], self.T,
+                                  _SAMPLE_MODES[mode])[0]
+            if mode == 'gumbel':
+                idx = pos                      # raw position (all switches are on when this mode is used)
+                self.switches[idx] = False
+            else:
+                idx = self.fink_ori_idx(pos)
+                self.reset_switches()
+        elif mode == 'random':
+            p = random.choice(range(nactive)) if rand_pos is None else int(rand_pos)
+            idx = self.fink_ori_idx(p)
+            self.reset_switches()
+        else:
+            raise ValueError('invalid sampling mode...')
+        return idx
+
+    def forward(self, x, sampling, mode, exp_noise=None, rand_pos=None):
+        pre, self._pre = self._pre, None
+        if sampling:
+            idx = pre if pre is not None else self.sample_index(mode, exp_noise, rand_pos)
+            self.last_idx = idx
+            op = self.m_ops[idx]
+            return MixedOpFn.apply(self._plan((idx,)), x, None, *op.hip_params()), 0
+        if pre is not None:
+            w, out_lat = pre
+        else:
+            if exp_noise is None:
+                exp_noise = torch.empty(8, device=x.device).exponential_()
+            lat = self.lat_tensor(x.size(-1), x.device)
+            W, CL = ArchFn.apply(exp_noise.reshape(1, 8).to(x.device), lat.reshape(1, 8), self.T, self.log_alphas)
+            w, out_lat = W[0], CL[0]
+        plan = self._plan(tuple(range(self.num_ops)))
+        out = MixedOpFn.apply(plan, x, w, *plan.params())
+        self.last_w = w
+        return out, out_lat
+
+
+class MixedStage(nn.Module):
+    def __init__(self, ics, ocs, ss, affs, acts, mc_num_ddict, lat_lookup, stage_type):
+        super().__init__()
+        self.lat_lookup = lat_lookup
+        self.mc_num_ddict = mc_num_ddict
+        self.stage_type = stage_type   # 0 for stage6 || 1 for stage1 || 2 for stage2 || 3 for stage3/4/5
+        self.start_res = 0 if ((ics[0] == ocs[0]) and (ss[0] == 1)) else 1
+        self.num_res = len(ics) - self.start_res + 1
+        nblocks = {0: 1, 1: 2, 2: 3, 3: 4}.get(stage_type)
+        if nblocks is None:
+            raise ValueError('invalid stage_type...')
+        self.nblocks = nblocks
+        for b in range(nblocks):
+            setattr(self, 'block%d' % (b + 1),
+                    MixedOP(ics[b], ocs[b], ss[b], affs[b], acts[b], len(PRIMITIVES), mc_num_ddict['block%d' % (b + 1)],
+                            lat_lookup))
+        self._initialize_betas()
+
+    def blocks(self):
+        return [getattr(self, 'block%d' % (b + 1)) for b in range(self.nblocks)]
+
+    def forward(self, x, sampling, mode, exp_noise=None, rand_pos=None):
+        res_list, lat_list = [x], []
+        for b, blk in enumerate(self.blocks()):
+            out, lat = blk(res_list[-1], sampling, mode,
+                           None if exp_noise is None else exp_noise[b],
+                           None if rand_pos is None else rand_pos[b])
+            res_list.append(out)
+            lat_list.append(lat)
+        res = res_list[self.start_res:]
+        if sampling:
+            cell_lat = None
+        else:
+            cell_lat = torch.stack(lat_list)
+            if self.start_res == 0:            # the stage input is a depth choice of latency 0
+                cell_lat = torch.cat([cell_lat.new_zeros(1), cell_lat])
+        out, out_lat = SinkFn.apply(self.betas, cell_lat, *res)
+        return out, out_lat
+
+    def _initialize_betas(self):
+        self.register_parameter('betas', nn.Parameter(torch.zeros((self.num_res))))
+
+
+class Network(nn.Module):
+    def __init__(self, num_classes, mc_num_dddict, lat_lookup):
+        super().__init__()
+        self.lat_lookup = lat_lookup
+        self.mc_num_dddict = mc_num_dddict
+
+        self.first_stem = ConvLayer(3, 32, kernel_size=3, stride=2, affine=False, act_func='relu')
+        self.second_stem = MBInvertedResBlock(32, 32, 8, 16, kernel_size=3, stride=1, affine=False, act_func='relu')
+        cfg = [
+            ('stage1', [16, 24], [24, 24], [2, 1], 'relu', 1),
+            ('stage2', [24, 40, 40], [40, 40, 40], [2, 1, 1], 'swish', 2),
+            ('stage3', [40, 80, 80, 80], [80, 80, 80, 80], [2, 1, 1, 1], 'swish', 3),
+            ('stage4', [80, 112, 112, 112], [112, 112, 112, 112], [1, 1, 1, 1], 'swish', 3),
+            ('stage5', [112, 192, 192, 192], [192, 192, 192, 192], [2, 1, 1, 1], 'swish', 3),
+            ('stage6', [192], [320], [1], 'swish', 0),
+        ]
+        self._stage_names = [c[0] for c in cfg]
+        for name, ics, ocs, ss, act, st in cfg:
+            setattr(self, name, MixedStage(ics=ics, ocs=ocs, ss=ss, affs=[False] * len(ics), acts=[act] * len(ics),
+                                           mc_num_ddict=mc_num_dddict[name], lat_lookup=lat_lookup, stage_type=st))
+        self.feature_mix_layer = ConvLayer(320, 1280, kernel_size=1, stride=1, affine=False, act_func='swish')
+        self.global_avg_pooling = nn.AdaptiveAvgPool2d(1)
+        self.classifier = LinearLayer(1280, num_classes)
+        self._initialization()
+        self._cells = None
+
+    def stages(self):
+        return [getattr(self, n) for n in self._stage_names]
+
+    def cells(self):
+        if self._cells is None:
+            self._cells = [blk for st in self.stages() for blk in st.blocks()]
+        return self._cells
+
+    def _prepare(self, x, sampling, mode, exp_noise, rand_pos):
+        """All arch-parameter work of one forward in ONE launch (and at most one device->host copy)."""
+        cells = self.cells()
+        n = len(cells)
+        dev = x.device
+        if not sampling:
+            if exp_noise is None:
+                exp_noise = torch.empty(n, 8, device=dev).exponential_()
+            size = x.size(-1)
+            lats = []
+            for st in self.stages():
+                for blk in st.blocks():
+                    lats.append(blk.lat_tensor(size, dev))
+                    size = (size - 1) // blk.stride + 1
+            T = cells[0].T
+            if any(c.T != T for c in cells):
+                raise ValueError('all MixedOPs must share one temperature (Network.set_temperature)')
+            W, CL = ArchFn.apply(exp_noise.to(dev), torch.stack(lats), T, *[c.log_alphas for c in cells])
+            for i, c in enumerate(cells):
+                c._pre = (W[i], CL[i])
+            return
+        if mode in _SAMPLE_MODES:
+            if mode.startswith('gumbel') and exp_noise is None:
+                exp_noise = torch.empty(n, 8, device=dev).exponential_()
+            pos = arch_sample([c.log_alphas for c in cells], [[int(s) for s in c.switches] for c in cells],
+                              None if exp_noise is None else exp_noise.to(dev), cells[0].T, _SAMPLE_MODES[mode])
+            for i, c in enumerate(cells):
+                c._pre = c.sample_index(mode, pos=pos[i])
+        elif mode == 'random':
+            for i, c in enumerate(cells):
+                c._pre = c.sample_index(mode, rand_pos=None if rand_pos is None else rand_pos[i])
+        else:
+            raise ValueError('invalid sampling mode...')
+
+    def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None):
+        out_lat = self.lat_lookup['base'] if not sampling else 0.0
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.first_stem(x)
+        x = self.second_stem(x)
+        self._prepare(x, sampling, mode, exp_noise, rand_pos)
+        for st in self.stages():
+            x, lat = st(x, sampling, mode)
+            out_lat += lat
+        x = self.feature_mix_layer(x)
+        x = self.global_avg_pooling(x)
+        x = x.view(x.size(0), -1)
+        x = self.classifier(x)
+        return x, out_lat
+
+    def set_temperature(self, T):
+        for m in self.modules():
+            if isinstance(m, MixedOP):
+                m.set_temperature(T)
+
+    def weight_parameters(self):
+        return [v for k, v in self.named_parameters() if not (k.endswith('log_alphas') or k.endswith('betas'))]
+
+    def arch_parameters(self):
+        return [v for k, v in self.named_parameters() if k.endswith('log_alphas') or k.endswith('betas')]
+
+    def log_alphas_parameters(self):
+        return [v for k, v in self.named_parameters() if k.endswith('log_alphas')]
+
+    def betas_parameters(self):
+        return [v for k, v in self.named_parameters() if k.endswith('betas')]
+
+    def reset_switches(self):
+        for m in self.modules():
+            if isinstance(m, MixedOP):
+                m.reset_switches()
+
+    def _initialization(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)) and m.bias is not None:
+                nn.init.constant_(m.bias, 0)

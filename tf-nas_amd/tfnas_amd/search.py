@@ -1,0 +1,126 @@
+"""The bi-level search iteration (reference: train_search.py:318-432) and its data-parallel form.
+
+``w_step`` / ``a_step`` restate the body of ``train_w_arch`` (weight step :370-385, architecture step
+:404-422) and ``train_wo_arch`` (:329-342) for a model with the reference's Network API; optimizers are the
+same torch.optim classes / hyper-parameters as train_search.py:197-206.
+
+Data parallelism (the reference only has single-process nn.DataParallel, effectively 1 GPU -- SURVEY.md 3.5
+quirk 16): one process per GPU, every rank runs the SAME sampled architecture and the SAME Gumbel noise on its
+own shard of the batch (noise comes from an identically-seeded host generator on every rank, so no broadcast
+is needed), BatchNorm statistics are per rank, and gradients are averaged with ONE flat all-reduce per step:
+weight grads of the sampled paths in the w-step (~35 MB, RCCL over xGMI), the 162 arch scalars in the alpha-step.
+Gradient clipping runs after the reduction, on the averaged gradients (train_search.py:383-384,416-417).
+"""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-4, a_betas=(0.5, 0.999)):
+    """train_search.py:197-206."""
+    opt_w = torch.optim.SGD(model.weight_parameters(), lr=w_lr, momentum=w_mom, weight_decay=w_wd)
+    opt_a = torch.optim.Adam(model.arch_parameters(), lr=a_lr, betas=a_betas, weight_decay=a_wd)
+    return opt_w, opt_a
+
+
+class SearchState:
+    """Caches the parameter lists the reference rebuilds from named_parameters() six times per step."""
+
+    def __init__(self, model):
+        self.model = model
+        self.weights = model.weight_parameters()
+        self.arch = model.arch_parameters()
+        self._mode = None
+
+    def require(self, weights, arch):
+        if self._mode != (weights, arch):
+            for p in self.weights:
+                p.requires_grad = weights
+            for p in self.arch:
+                p.requires_grad = arch
+            self._mode = (weights, arch)
+
+
+def allreduce_mean_(tensors, group=None):
+    """Average a list of tensors across ranks with one flat all-reduce (no-op when not distributed)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+class NoiseSource:
+    """Exp(1) draws / random positions from a host generator.  Seeding every rank identically makes all ranks
+    sample the same architecture without communication."""
+
+    def __init__(self, seed, ncell=18):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.rng = random.Random(seed)
+        self.ncell = ncell
+
+    def exp(self, device):
+        return torch.empty(self.ncell, 8).exponential_(generator=self.gen).to(device, non_blocking=True)
+
+    def rand_pos(self):
+        # position among the 7 candidates left after the gumbel pass (model_search.py:78-81)
+        return [self.rng.randrange(7) for _ in range(self.ncell)]
+
+
+def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, bi_sampling=True, group=None):
+    """Weight step: CE(gumbel path) [+ CE(random path)] -> backward -> (all-reduce) -> clip -> SGD."""
+    model = state.model
+    state.require(True, False)
+    logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g)
+    loss = F.cross_entropy(logits_g, target)
+    if bi_sampling:
+        logits_r, _ = model(x, True, 'random', rand_pos=rand_pos)
+        loss = loss + F.cross_entropy(logits_r, target)
+    else:
+        model.reset_switches()
+    opt_w.zero_grad()
+    loss.backward()
+    grads = [p.grad for p in state.weights if p.grad is not None]
+    allreduce_mean_(grads, group)
+    if grad_clip > 0:
+        nn.utils.clip_grad_norm_(state.weights, grad_clip)
+    opt_w.step()
+    return loss.detach(), logits_g.detach()
+
+
+def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0, noise=None, group=None):
+    """Architecture step: CE + lambda*|lat/target-1| -> backward -> (all-reduce) -> clip -> Adam -> log-softmax
+    projection of alphas AND betas (train_search.py:421-422)."""
+    model = state.model
+    state.require(False, True)
+    logits, lat = model(x, False, exp_noise=noise)
+    loss_a = F.cross_entropy(logits, target)
+    loss_l = torch.abs(lat / target_lat - 1.) * lambda_lat
+    loss = loss_a + loss_l
+    opt_a.zero_grad()
+    loss.backward()
+    allreduce_mean_([p.grad for p in state.arch if p.grad is not None], group)
+    grads = [p.grad.detach().clone() for p in state.arch]
+    if grad_clip > 0:
+        nn.utils.clip_grad_norm_(state.arch, grad_clip)
+    opt_a.step()
+    for p in state.arch:
+        p.data = F.log_softmax(p.detach().data, dim=-1)
+    return loss_a.detach(), loss_l.detach(), lat.detach(), grads
+
+
+def search_iteration_pair(state, opt_w, opt_a, batches_w, batch_a, noise, target_lat=15.0, lambda_lat=0.1,
+                          grad_clip=5.0, group=None):
+    """Two consecutive iterations of train_w_arch: w-step, alpha-step (even step), w-step."""
+    dev = batches_w[0][0].device
+    w_step(state, batches_w[0][0], batches_w[0][1], opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
+    a_step(state, batch_a[0], batch_a[1], opt_a, target_lat, lambda_lat, grad_clip, noise.exp(dev), group=group)
+    w_step(state, batches_w[1][0], batches_w[1][1], opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
