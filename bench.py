@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Benchmark of the TF-NAS supernet search step on MI355X (BASELINE.json metric: search images/sec).
+
+A "step" here is one ITERATION PAIR of the reference's train_w_arch loop (train_search.py:366-426):
+w-step on a train batch, alpha-step on a val batch (every even iteration), w-step on the next train batch --
+i.e. 2*B train images (and B val images) per step per GPU.  `value` = train images consumed per second by the
+whole job (all ranks), inputs already resident in HBM, optimizer steps / clipping / projection included.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3                  (single GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant HIP kernel family of the timed region, timed live with HIP events on the launch
+                stream (tfnas_prof_* hooks), vs its algorithmic flops / HBM bytes.
+  cpu_baseline  the CPU oracle (plain PyTorch restatement, proven equal to the reference) timed on this host's
+                cores on a bounded sample of the same loop at the reference's batch 32 (N=1, rank 0 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'tf-nas_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_FP32_MFMA_TF = 157.3    # v_mfma_f32_16x16x4_f32 rate (== fp32 vector peak)
+
+
+def cell_table(B):
+    """(name, N, H, W, ic, oc, stride, mids) of the 18 cells at initial widths."""
+    from tfnas_amd import geometry as g
+    rows = []
+    for stage, block, ic, oc, s, act, size in g.iter_cells():
+        mids = [g.init_mid_channels(ic, i) for i in range(8)]
+        rows.append((stage + '.' + block, B, size, size, ic, oc, s, mids))
+    return rows
+
+
+def family_algorithmic(fam, B):
+    """Algorithmic (flops, bytes) summed over the launches one iteration pair makes of kernel family `fam`,
+    plus the launch count.  alpha-step: all 8 candidates of the 18 cells; w-step: 2 paths x 18 cells x 1
+    candidate x 2 w-steps (expected value over uniform candidate choice).  fp32 = 4 B/element.
+    Only families that can dominate are modelled; others return None."""
+    from tfnas_amd import geometry as g
+    fl = by = 0.0
+    n = 0
+    for name, N, H, W, ic, oc, s, mids in cell_table(B):
+        P, Po = N * H * W, N * ((H - 1) // s + 1) * ((W - 1) // s + 1)
+        Msoft = sum(mids)
+        Mavg = Msoft / 8.0
+        for M, launches in ((Msoft, 1), (Mavg, 4)):          # soft launch once, sampled launch 4x per pair
+            G = 8 if launches == 1 else 1
+            if fam == 'k_expand_fwd':
+                f, b = 2.0 * P * ic * M, 4.0 * (P * ic + P * M + M * ic)
+            elif fam == 'k_project_fwd':
+                f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + G * Po * oc + M * oc)
+            elif fam == 'k_project_dgrad':
+                f, b = 2.0 * Po * M * oc, 4.0 * (2 * G * Po * oc + Po * M + M * oc)
+            elif fam == 'k_expand_dgrad':
+                f, b = 2.0 * P * M * ic, 4.0 * (2 * P * M + P * ic + M * ic)
+            elif fam == 'k_dw_fwd':
+                kk = 17.0                                      # mean of 9 and 25 taps
+                f, b = 2.0 * Po * M * kk, 4.0 * (P * M + Po * M)
+            elif fam == 'k_dw_bwd_data':
+                kk = 17.0
+                f, b = 2.0 * P * M * kk / (s * s), 4.0 * (2 * Po * M + 2 * P * M)
+            elif fam == 'k_bn2_bwd':
+                f, b = 8.0 * Po * M, 4.0 * (3 * Po * M)
+            elif fam in ('k_project_wgrad', 'k_expand_wgrad', 'k_dw_wgrad'):
+                if launches == 1:
+                    continue                                   # no weight grads in the alpha-step
+                if fam == 'k_project_wgrad':
+                    f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + 2 * Po * oc)
+                elif fam == 'k_expand_wgrad':
+                    f, b = 2.0 * P * M * ic, 4.0 * (2 * P * M + P * ic)
+                else:
+                    f, b = 2.0 * Po * M * 17.0, 4.0 * (2 * Po * M + P * M)
+            else:
+                return None
+            fl += f * launches
+            by += b * launches
+            n += launches
+    return fl, by, n
+
+
+def run_gpu(args):
+    from tfnas_amd import Network, load_lat_lookup, geometry, search, _lib
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    B = args.batch
+    torch.manual_seed(2)
+    model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
+    model.set_temperature(5.0)
+    state = search.SearchState(model)
+    opt_w, opt_a = search.make_optimizers(model)
+    noise = search.NoiseSource(2)                                  # same seed on every rank -> same architectures
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # each rank its own shard of synthetic data
+    pool = 4
+
+    def batch():
+        return (torch.randn(B, 3, 224, 224, device=dev, generator=gen).contiguous(memory_format=torch.channels_last),
+                torch.randint(0, 100, (B,), device=dev, generator=gen))
+    train = [batch() for _ in range(2 * pool)]
+    val = [batch() for _ in range(pool)]
+
+    def pair(i):
+        search.search_iteration_pair(state, opt_w, opt_a, (train[(2 * i) % len(train)], train[(2 * i + 1) % len(train)]),
+                                     val[i % len(val)], noise)
+
+    lib = _lib.lib()
+    nfam = lib.tfnas_prof_count()
+    names = [lib.tfnas_prof_name(i).decode() for i in range(nfam)]
+
+    def collect():
+        out = {}
+        for i in range(nfam):
+            cnt, ms = C.c_uint64(0), C.c_double(0.0)
+            _lib.check(lib.tfnas_prof_collect(i, C.byref(cnt), C.byref(ms)), 'tfnas_prof_collect')
+            out[names[i]] = (cnt.value, ms.value)
+        return out
+
+    for i in range(max(args.warmup - 1, 0)):
+        pair(i)
+    # last warmup pair: time every kernel family to find the dominant one
+    lib.tfnas_prof_enable((1 << nfam) - 1)
+    pair(args.warmup)
+    torch.cuda.synchronize()
+    fam_ms = collect()
+    lib.tfnas_prof_enable(0)
+    dominant = max(fam_ms, key=lambda k: fam_ms[k][1])
+    lib.tfnas_prof_enable(1 << names.index(dominant))               # only the dominant family in the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pair(args.warmup + 1 + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    dom = collect()[dominant]
+    lib.tfnas_prof_enable(0)
+
+    result = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = 2.0 * B * world * args.steps / dt
+        alg = family_algorithmic(dominant, B)
+        roof = None
+        if alg is not None and dom[0] > 0:
+            fl, by, nl = alg
+            avg_ms = dom[1] / dom[0]
+            tf = fl / nl / (avg_ms * 1e-3) / 1e12
+            gbs = by / nl / (avg_ms * 1e-3) / 1e9
+            if tf / PEAK_FP32_MFMA_TF >= gbs / PEAK_HBM_GBS:
+                roof = dict(bound='mfma', achieved=round(tf, 2), peak=PEAK_FP32_MFMA_TF, unit='TFLOP/s',
+                            frac=round(tf / PEAK_FP32_MFMA_TF, 4))
+            else:
+                roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                            frac=round(gbs / PEAK_HBM_GBS, 4))
+            roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 4), launches_timed=dom[0],
+                        alg_flops_per_launch=fl / nl, alg_bytes_per_launch=by / nl, traffic=None,
+                        share_of_step=round(dom[1] / args.steps / ms_per_step, 3))
+        result = dict(metric='supernet search images/sec (w-step + alpha-step)', value=round(value, 2), unit='images/s',
+                      n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
+                      higher_is_better=True, scaling='weak', vs_baseline=None, dtype='fp32', data='synthetic',
+                      config=dict(workload='TF-NAS supernet search iteration pair (w-step, alpha-step, w-step; '
+                                           'train_search.py:366-426) on ImageNet-100-shaped 224x224 batches, '
+                                           'initial widths, T=5, target_lat=15 (BASELINE configs[1] geometry, fp32)',
+                                  batch_per_gpu=B, global_batch=B * world, train_images_per_step=2 * B * world,
+                                  parallelism='dp%d' % world),
+                      roofline=roof,
+                      kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
+                                          if v[0]})
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+def run_cpu_baseline(seconds_budget=25.0, B=32):
+    """Time the CPU oracle on a bounded sample: 1 warm-up + up to 2 iteration pairs at the reference's B=32."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import tfnas_oracle as orc
+    from tfnas_amd.latency import load_lat_lookup
+    from tfnas_amd import search
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(2)
+    model = orc.Network(100, orc.initial_mc_num_dddict(), load_lat_lookup('gpu'))
+    model.set_temperature(5.0)
+    opt_w, opt_a = orc.make_optimizers(model)
+    noise = search.NoiseSource(2)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(B, 3, 224, 224, generator=g) for _ in range(3)]
+    ys = [torch.randint(0, 100, (B,), generator=g) for _ in range(3)]
+
+    def pair():
+        orc.w_step(model, xs[0], ys[0], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
+        orc.a_step(model, xs[1], ys[1], opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
+        orc.w_step(model, xs[2], ys[2], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
+    t0 = time.perf_counter()
+    pair()                                   # warm-up (oneDNN primitive creation)
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while n < 2 and (n == 0 or (time.perf_counter() - t0) + warm < seconds_budget):
+        pair()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=round(2 * B / dt, 3), unit='images/s', cores=threads, kind='port',
+                sample='%d iteration pair(s) (w-step, alpha-step, w-step) of oracle/tfnas_oracle.py at batch %d fp32 '
+                       'after 1 warm-up pair, torch %s, %d threads' % (n, B, torch.__version__, threads),
+                ms_per_step=round(dt * 1e3, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step-half (BASELINE configs[1]: 128)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    res = run_gpu(args)
+    if res is not None:
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = run_cpu_baseline()
+        print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

@@ -95,8 +95,8 @@ typedef struct TfnasCellWs {
     uint64_t dEh;      /* floats  [N*H*W][M]                                                */
     uint64_t bsmall;   /* floats  dgate[N][M] | dpooled[N][M] | dgl[N][M] | dhpre[N][SE] | cb1[M][4] */
     uint64_t off_dgate, off_dpooled, off_dgl, off_dhpre, off_cb1;
-    uint64_t red;      /* doubles red3[G*oc][2] | red2[M][2] | red1[M][2]                   */
-    uint64_t off_red3, off_red2, off_red1;
+    uint64_t red;      /* doubles red3[G*oc][2] | red2[M][2] | red1[M][2] | resdot[2]       */
+    uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = <dout, x> of residual cells */
     uint64_t dx;       /* floats  [N*H*W][ic]                                               */
 } TfnasCellWs;
 
@@ -164,6 +164,15 @@ int tfnas_sink_fwd(int K, const float *betas, const float *const *res, const flo
 int tfnas_sink_bwd(int K, const float *bw, const float *const *res, const float *cell_lat, const float *dout,
                    const float *dlat, uint64_t count, float *const *dres, float *dbetas, float *dcell_lat,
                    double *dot_scratch, void *stream);
+
+/* ---- optional diagnostics (used by bench.py for the `roofline` object) --------------------------------------
+ * Per-kernel-family timing with HIP events recorded on the launch stream.  tfnas_prof_enable(mask) turns the
+ * families whose bit is set on (0 = off, the default); tfnas_prof_collect() waits for the recorded events of
+ * one family, returns their count and summed duration in ms, and clears them.  Not re-entrant. */
+int tfnas_prof_enable(unsigned mask);
+int tfnas_prof_count(void);
+const char *tfnas_prof_name(int id);
+int tfnas_prof_collect(int id, uint64_t *launches, double *total_ms);
 
 #ifdef __cplusplus
 }

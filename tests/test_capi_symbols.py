@@ -1,0 +1,94 @@
+"""CPU-side checks of the C-ABI shared library: it loads without a GPU, exports every function that
+include/tfnas_hip.h declares, the ctypes struct layouts match, and the host-only planning entry points work."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'tfnas_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from tfnas_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.lib()
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'^\s*(?:int|uint64_t|const char \*)\s*(tfnas_\w+)\s*\(', src, flags=re.M)))
+
+
+def test_header_functions_are_all_exported_and_bound(lib):
+    from tfnas_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), 'symbol %s declared in include/tfnas_hip.h is not exported' % n
+    assert sorted(_lib.exported_names()) == names
+
+
+def test_struct_layouts(lib):
+    from tfnas_amd import _lib
+    assert lib.tfnas_abi_version() == 1
+    assert lib.tfnas_sizeof(0) == C.sizeof(_lib.TfnasGroup)
+    assert lib.tfnas_sizeof(1) == C.sizeof(_lib.TfnasCellDesc)
+    assert lib.tfnas_sizeof(2) == C.sizeof(_lib.TfnasCellWs)
+
+
+def _desc(N=2, H=9, W=11, ic=24, oc=24, stride=1, mids=(32, 53), ks=(3, 5), ses=(0, 24)):
+    from tfnas_amd import _lib
+    d = _lib.TfnasCellDesc()
+    d.N, d.H, d.W, d.ic, d.oc, d.stride, d.act, d.has_res, d.G = N, H, W, ic, oc, stride, 1, int(ic == oc and stride == 1), len(mids)
+    d.eps = 1e-5
+    for g, (m, k, s) in enumerate(zip(mids, ks, ses)):
+        d.g[g].mc, d.g[g].k, d.g[g].se = m, k, s
+    return d
+
+
+def test_plan_and_workspace_geometry(lib):
+    from tfnas_amd import _lib
+    d = _desc()
+    assert lib.tfnas_cell_plan(C.byref(d)) == 0
+    assert (d.Ho, d.Wo) == (9, 11)
+    assert [d.g[0].mcp, d.g[1].mcp, d.g[0].off, d.g[1].off, d.M, d.SE] == [32, 56, 0, 32, 88, 24]
+    ws = _lib.TfnasCellWs()
+    assert lib.tfnas_cell_ws(C.byref(d), C.byref(ws)) == 0
+    P = 2 * 9 * 11
+    assert (ws.E, ws.D, ws.Pr, ws.out, ws.dx) == (P * 88, P * 88, 2 * P * 24, P * 24, P * 24)
+    assert ws.stats == 4 * 88 + 2 * 2 * 24 and ws.off_stats3 == 4 * 88
+    d2 = _desc(H=112, W=112, ic=16, oc=24, stride=2)
+    assert lib.tfnas_cell_plan(C.byref(d2)) == 0 and (d2.Ho, d2.Wo) == (56, 56)
+    d3 = _desc(H=9, W=13, ic=24, oc=40, stride=2)
+    assert lib.tfnas_cell_plan(C.byref(d3)) == 0 and (d3.Ho, d3.Wo) == (5, 7)       # odd extents, pad k//2
+
+
+def test_error_codes(lib):
+    from tfnas_amd import _lib
+    assert lib.tfnas_cell_plan(None) == -2
+    assert lib.tfnas_cell_plan(C.byref(_desc(ic=22))) == -1          # ic % 4
+    assert lib.tfnas_cell_plan(C.byref(_desc(stride=3))) == -1
+    assert lib.tfnas_cell_plan(C.byref(_desc(ks=(3, 7)))) == -1
+    bad = _desc()
+    bad.G = 9
+    assert lib.tfnas_cell_plan(C.byref(bad)) == -3
+    d = _desc()
+    lib.tfnas_cell_plan(C.byref(d))
+    # NULL buffers are rejected before any launch (no GPU needed)
+    assert lib.tfnas_mixedop_fwd(C.byref(d), None, None, None, None, None, None, None, None, None) == -2
+    assert lib.tfnas_arch_fwd(0, None, None, None, 1.0, None, None, None) == -3
+    assert lib.tfnas_sink_fwd(5, None, None, None, 8, None, None, None, None) == -3
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from tfnas_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
+        _lib.lib()

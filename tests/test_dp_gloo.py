@@ -1,0 +1,126 @@
+"""Data-parallel logic with world_size=2 on CPU (gloo).  The compute model here is the CPU oracle (tests may
+use it); what is under test is tfnas_amd.search's flat gradient all-reduce, shared noise source and the
+clip-after-reduce order."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    for p in (os.path.join(ROOT, 'tf-nas_amd'), os.path.join(ROOT, 'oracle')):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import tfnas_oracle as orc
+    from tfnas_amd import search
+    from tfnas_amd.latency import load_lat_lookup
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(2)
+    model = orc.Network(100, orc.initial_mc_num_dddict(), load_lat_lookup('gpu'))
+    model.set_temperature(5.0)
+    state = search.SearchState(model)
+    opt_w, opt_a = search.make_optimizers(model)
+    noise = search.NoiseSource(7)                  # same seed on every rank -> same architecture, no broadcast
+    g = torch.Generator().manual_seed(100)         # same global batch everywhere; each rank takes its shard
+    X = torch.randn(2 * world, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 100, (2 * world,), generator=g)
+    xs, ys = X[2 * rank:2 * rank + 2], Y[2 * rank:2 * rank + 2]
+    search.w_step(state, xs, ys, opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
+    gidx = [c.last_idx for c in model.cells()]
+    _, _, lat, grads = search.a_step(state, xs, ys, opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
+    torch.save(dict(arch=[p.detach().clone() for p in model.arch_parameters()],
+                    wsum=[float(p.detach().double().sum()) for p in model.weight_parameters()],
+                    grads=grads, gidx=gidx, lat=float(lat)), os.path.join(outdir, 'r%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def _single_process_reference(world):
+    """What 2 ranks should equal: per-shard forward/backward (per-shard BN statistics), grads averaged, then
+    clip + step once."""
+    for p in (os.path.join(ROOT, 'tf-nas_amd'), os.path.join(ROOT, 'oracle')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import tfnas_oracle as orc
+    from tfnas_amd import search
+    from tfnas_amd.latency import load_lat_lookup
+    torch.manual_seed(2)
+    model = orc.Network(100, orc.initial_mc_num_dddict(), load_lat_lookup('gpu'))
+    model.set_temperature(5.0)
+    opt_w, opt_a = search.make_optimizers(model)
+    noise = search.NoiseSource(7)
+    g = torch.Generator().manual_seed(100)
+    X = torch.randn(2 * world, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 100, (2 * world,), generator=g)
+    ng, rp = noise.exp('cpu'), noise.rand_pos()
+    orc._set_requires_grad(model, True, False)
+    opt_w.zero_grad()
+    for r in range(world):
+        xs, ys = X[2 * r:2 * r + 2], Y[2 * r:2 * r + 2]
+        lg, _ = model(xs, True, 'gumbel', exp_noise=ng)
+        lr_, _ = model(xs, True, 'random', rand_pos=rp)
+        ((F.cross_entropy(lg, ys) + F.cross_entropy(lr_, ys)) / world).backward()
+    nn.utils.clip_grad_norm_(model.weight_parameters(), 5.0)
+    opt_w.step()
+    na = noise.exp('cpu')
+    orc._set_requires_grad(model, False, True)
+    opt_a.zero_grad()
+    for r in range(world):
+        xs, ys = X[2 * r:2 * r + 2], Y[2 * r:2 * r + 2]
+        l, lat = model(xs, False, exp_noise=na)
+        ((F.cross_entropy(l, ys) + torch.abs(lat / 15.0 - 1.) * 0.1) / world).backward()
+    grads = [p.grad.detach().clone() for p in model.arch_parameters()]
+    nn.utils.clip_grad_norm_(model.arch_parameters(), 5.0)
+    opt_a.step()
+    for p in model.arch_parameters():
+        p.data = F.log_softmax(p.detach().data, dim=-1)
+    return model, grads
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_equals_shardwise_average(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'r0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'r1.pt'))
+    assert r0['gidx'] == r1['gidx']                         # same sampled architecture on every rank
+    for a, b in zip(r0['arch'], r1['arch']):
+        assert torch.equal(a, b)                            # replicas stay bit-identical
+    assert r0['wsum'] == r1['wsum']
+    ref, ref_grads = _single_process_reference(world)
+    for a, b in zip(r0['grads'], ref_grads):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4)    # thread-count dependent fp32 summation order
+    for a, b in zip(r0['arch'], ref.arch_parameters()):
+        assert torch.allclose(a, b.detach(), atol=2e-5)
+    for a, p in zip(r0['wsum'], ref.weight_parameters()):
+        assert abs(a - float(p.detach().double().sum())) < 1e-3 + 1e-5 * abs(a)
+
+
+def test_allreduce_is_noop_without_process_group():
+    from tfnas_amd import search
+    t = [torch.ones(3), torch.arange(4.)]
+    search.allreduce_mean_(t)
+    assert torch.equal(t[0], torch.ones(3))
+
+
+def test_noise_source_is_rank_independent():
+    from tfnas_amd import search
+    a, b = search.NoiseSource(3), search.NoiseSource(3)
+    assert torch.equal(a.exp('cpu'), b.exp('cpu')) and a.rand_pos() == b.rand_pos()
+    assert all(0 <= p < 7 for p in a.rand_pos())

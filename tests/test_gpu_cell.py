@@ -1,0 +1,110 @@
+"""GPU parity: every stage of the HIP MixedOP (through the C ABI) against the CPU oracle, fp32.
+Tolerance: abs err <= 2e-5 + 1e-3 * max|ref| per tensor (north_star: 1e-3 fp32; observed ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden
+import _hipcheck as hc
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # name, ic, oc, stride, act, H, W, N, mids
+    ('tiny_s1_relu_res', 24, 24, 1, 'relu', 9, 11, 2, [32, 52, 28, 56, 36, 60, 40, 64]),
+    ('tiny_s2_relu', 16, 24, 2, 'relu', 12, 10, 2, [24, 40, 20, 36, 28, 44, 24, 48]),
+    ('tiny_s2_swish_odd', 24, 40, 2, 'swish', 9, 13, 2, [36, 72, 40, 60, 32, 64, 44, 68]),
+    ('tiny_ragged_res', 40, 40, 1, 'swish', 8, 6, 3, [53, 107, 44, 88, 61, 96, 48, 79]),
+    ('tiny_7x7', 32, 48, 1, 'swish', 7, 7, 3, [40, 72, 36, 64, 44, 80, 52, 68]),
+    ('tiny_1x1_img', 16, 16, 1, 'swish', 1, 1, 5, [20, 33, 24, 40, 17, 35, 28, 44]),      # degenerate spatial extent
+    ('wide_tile_edge', 16, 24, 2, 'relu', 37, 41, 1, [48, 96] * 4),                         # tiles with ragged borders
+    ('real_s1b1_112', 16, 24, 2, 'relu', 112, 112, 1, [48, 96] * 4),
+    ('real_s1b2_56', 24, 24, 1, 'relu', 56, 56, 2, [72, 144] * 4),
+    ('real_s2b2_28', 40, 40, 1, 'swish', 28, 28, 2, [120, 240] * 4),
+    ('real_s3b1_28', 40, 80, 2, 'swish', 28, 28, 2, [120, 240] * 4),
+    ('real_s4b2_14', 112, 112, 1, 'swish', 14, 14, 2, [336, 672] * 4),
+    ('real_s5b1_14', 112, 192, 2, 'swish', 14, 14, 2, [336, 672] * 4),
+    ('real_s5b2_7', 192, 192, 1, 'swish', 7, 7, 4, [576, 1152] * 4),
+    ('real_s6b1_7', 192, 320, 1, 'swish', 7, 7, 4, [576, 1152] * 4),
+    ('max_width_7', 192, 192, 1, 'swish', 7, 7, 2, [768, 1536] * 4),                        # elasticity upper bound
+]
+
+
+def _inputs(cfg):
+    name, ic, oc, s, act, H, W, N, mids = cfg
+    o, m = hc.make_cell_pair(ic, oc, s, act, mids, seed=len(name))
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, ic, H, W, generator=g)
+    r = torch.randn(N, oc, (H - 1) // s + 1, (W - 1) // s + 1, generator=g)
+    e = torch.empty(8).exponential_(generator=g)
+    return o, m, x, r, e
+
+
+@pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_soft_mode_all_stages(cfg):
+    o, m, x, r, e = _inputs(cfg)
+    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=False)
+    assert not hc.worst(res), hc.worst(res)
+
+
+@pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
+@pytest.mark.parametrize('idx', [0, 3, 5, 6])
+def test_sampled_mode_with_weight_grads(cfg, idx):
+    o, m, x, r, e = _inputs(cfg)
+    res = hc.compare_cell(o, m, x, r, e, [idx], need_wgrad=True)
+    assert not hc.worst(res), hc.worst(res)
+
+
+def test_soft_mode_also_gives_weight_grads_when_asked():
+    """autograd semantics: if weights require grad in soft mode, all 8 candidates get gradients."""
+    o, m, x, r, e = _inputs(CONFIGS[0])
+    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=True)
+    assert not hc.worst(res), hc.worst(res)
+
+
+def test_forward_is_deterministic_and_linear_in_mix_weights():
+    """size-independent properties: same input -> bit-identical output; out(w) is linear in w."""
+    from tfnas_amd.functions import MixedOpFn
+    o, m, x, r, e = _inputs(CONFIGS[8])
+    xm = x.cuda().contiguous(memory_format=torch.channels_last)
+    plan = m._plan(tuple(range(8)))
+    ps = plan.params()
+    w1 = torch.softmax(torch.randn(8), 0).cuda()
+    w2 = torch.softmax(torch.randn(8), 0).cuda()
+    with torch.no_grad():
+        a = MixedOpFn.apply(plan, xm, w1, *ps)
+        a2 = MixedOpFn.apply(plan, xm, w1, *ps)
+        b = MixedOpFn.apply(plan, xm, w2, *ps)
+        c = MixedOpFn.apply(plan, xm, 0.25 * w1 + 0.75 * w2, *ps)
+    assert torch.equal(a, a2)
+    assert torch.allclose(c, 0.25 * a + 0.75 * b, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', _golden.CELL_NAMES)
+def test_hip_cell_matches_committed_reference_vectors(name):
+    """HIP path vs golden vectors captured from the REFERENCE itself (tests/golden/cell_*.npz)."""
+    from tfnas_amd.model_search import MixedOP
+    fx = _golden.load('cell_%s.npz' % name)
+    oc_cell = _golden.oracle_cell_from(fx)
+    ic, oc, s, H, W, B = [int(v) for v in fx['geom']]
+    m = MixedOP(ic, oc, s, False, str(fx['act']), 8, oc_cell.mc_num_dict, _golden.cell_lut_for(fx))
+    m.load_state_dict(oc_cell.state_dict())
+    m = m.cuda()
+    m.set_temperature(float(fx['T']))
+    x = torch.from_numpy(fx['x']).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out, lat = m(x, False, None, exp_noise=torch.from_numpy(fx['e']).cuda())
+    assert np.allclose(out.detach().cpu().numpy(), fx['soft_out'], atol=1e-4, rtol=1e-3)
+    assert abs(float(lat) - float(fx['soft_lat'])) < 1e-5
+    ((out * torch.from_numpy(fx['r']).cuda()).sum() + 3.0 * lat).backward()
+    assert np.allclose(x.grad.cpu().numpy(), fx['soft_dx'], atol=1e-4, rtol=1e-3)
+    assert np.allclose(m.log_alphas.grad.cpu().numpy(), fx['soft_dalpha'], atol=3e-4, rtol=1e-3)
+    for idx in (1, 6):
+        m.zero_grad()
+        xs = torch.from_numpy(fx['x']).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        o_ = m.m_ops[idx](xs)
+        assert np.allclose(o_.detach().cpu().numpy(), fx['samp%d_out' % idx], atol=1e-4, rtol=1e-3)
+        (o_ * torch.from_numpy(fx['r']).cuda()).sum().backward()
+        assert np.allclose(xs.grad.cpu().numpy(), fx['samp%d_dx' % idx], atol=1e-4, rtol=1e-3)
+        for k, p in m.m_ops[idx].named_parameters():
+            want = fx['samp%d_g.%s' % (idx, k)]
+            assert np.allclose(p.grad.cpu().numpy(), want, atol=1e-4 + 1e-4 * abs(want).max(), rtol=1e-3), k

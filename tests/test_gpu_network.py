@@ -1,0 +1,133 @@
+"""GPU parity of the whole supernet + the bi-level search iteration against the CPU oracle (fp32).
+
+Gates (SURVEY.md 8(d) "parity gates"): logits / mixed-op activations <= 1e-3, sampled indices identical,
+expected-latency scalar <= 1e-3 ms, single-step (teacher-forced) arch gradients <= 1e-4 abs and post-step
+alpha/beta <= 1e-3; free-running trajectory judged with the step-dependent tolerance of SURVEY.md 3.6."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import _golden
+import tfnas_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lut():
+    from tfnas_amd.latency import load_lat_lookup
+    return load_lat_lookup('gpu')
+
+
+def _pair(lut, seed=2, T=5.0):
+    from tfnas_amd import Network, geometry
+    torch.manual_seed(seed)
+    o = orc.Network(100, orc.initial_mc_num_dddict(), lut)
+    torch.manual_seed(seed)
+    m = Network(100, geometry.initial_mc_num_dddict(), lut)
+    for (ka, a), (kb, b) in zip(o.state_dict().items(), m.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+    o.set_temperature(T); m.set_temperature(T)
+    return o, m.cuda()
+
+
+def test_soft_forward_logits_latency_and_arch_grads(lut):
+    o, m = _pair(lut)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (4,), generator=g)
+    noise = torch.empty(18, 8).exponential_(generator=g)
+    for p in o.weight_parameters() + m.weight_parameters():
+        p.requires_grad = False
+    lo, lato = o(x, False, exp_noise=noise)
+    lm, latm = m(x.cuda(), False, exp_noise=noise.cuda())
+    assert torch.allclose(lm.cpu(), lo, atol=1e-3, rtol=1e-3), float((lm.cpu() - lo).abs().max())
+    assert abs(float(latm) - float(lato)) < 1e-3
+    for mod, l, lat, yy in ((o, lo, lato, y), (m, lm, latm, y.cuda())):
+        (torch.nn.functional.cross_entropy(l, yy) + torch.abs(lat / 15.0 - 1.) * 0.1).backward()
+    for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
+        if k.endswith('log_alphas') or k.endswith('betas'):
+            assert torch.allclose(b.grad.cpu(), a.grad, atol=1e-4), (k, float((b.grad.cpu() - a.grad).abs().max()))
+
+
+def test_zero_noise_latency_known_answer(lut):
+    _, m = _pair(lut)
+    with torch.no_grad():
+        _, lat = m(torch.zeros(2, 3, 224, 224).cuda(), False, exp_noise=torch.ones(18, 8).cuda())
+    assert abs(float(lat) - 10.806680679) < 1e-4            # SURVEY.md 8(c).3, data independent
+
+
+def test_bisampling_indices_and_logits(lut):
+    z = _golden.load('network.npz')
+    o, m = _pair(lut)
+    g = torch.Generator().manual_seed(int(z['samp_x_seed']))
+    noise = torch.empty(18, 8).exponential_(generator=g)
+    x = torch.randn(1, 3, 224, 224, generator=g)
+    x4 = torch.cat([x, torch.randn(3, 3, 224, 224, generator=g)])
+    random.seed(int(z['samp_random_seed']))
+    rp = [random.choice(range(7)) for _ in range(18)]
+    with torch.no_grad():
+        lg, _ = m(x4.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+        gidx = [c.last_idx for c in m.cells()]
+        assert gidx == z['samp_gumbel_idx'].tolist()          # indices the REFERENCE picked for this noise
+        lr_, _ = m(x4.cuda(), True, 'random', rand_pos=rp)
+        ridx = [c.last_idx for c in m.cells()]
+        og, _ = o(x4, True, 'gumbel', exp_noise=noise)
+        orr, _ = o(x4, True, 'random', rand_pos=rp)
+    assert [c.last_idx for c in o.cells()] == ridx and all(a != b for a, b in zip(gidx, ridx))
+    assert all(all(c.switches) for c in m.cells())
+    assert torch.allclose(lg.cpu(), og, atol=1e-3, rtol=1e-3)
+    assert torch.allclose(lr_.cpu(), orr, atol=1e-3, rtol=1e-3)
+    with pytest.raises(ValueError):
+        m(x4.cuda(), True, 'max')
+
+
+def _sync_state(o, m, oo, mo):
+    """teacher forcing: copy oracle params + optimizer state into the HIP model"""
+    m.load_state_dict(o.state_dict())
+    for (opt_o, opt_m) in zip(oo, mo):
+        sd = opt_o.state_dict()
+        opt_m.load_state_dict(sd)
+        for st in opt_m.state.values():
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.dim() > 0:
+                    st[k] = v.cuda()
+
+
+def test_search_steps_teacher_forced_and_free_running(lut):
+    from tfnas_amd import search
+    o, m = _pair(lut)
+    oo = orc.make_optimizers(o)
+    mo = search.make_optimizers(m)
+    st = search.SearchState(m)
+    g = torch.Generator().manual_seed(5)
+    B, iters = 4, 6
+    tol = {1: 1e-3, 2: 1e-3, 3: 2e-3}                      # 2e-3 * 3^(k-3) for alpha-step k >= 3
+    k = 0
+    for it in range(iters):
+        x = torch.randn(B, 3, 224, 224, generator=g)
+        y = torch.randint(0, 100, (B,), generator=g)
+        ng = torch.empty(18, 8).exponential_(generator=g)
+        rp = [int(v) for v in torch.randint(0, 7, (18,), generator=g)]
+        lo_, _, gi, ri = orc.w_step(o, x, y, oo[0], 5.0, noise_g=ng, rand_pos=rp)
+        lm_, _ = search.w_step(st, x.cuda(), y.cuda(), mo[0], 5.0, noise_g=ng.cuda(), rand_pos=rp)
+        assert abs(float(lo_) - float(lm_)) < 2e-3 * max(1, it)
+        if it % 2 == 0:
+            k += 1
+            na = torch.empty(18, 8).exponential_(generator=g)
+            if it == 0:
+                # strict single-step gate from identical state
+                _sync_state(o, m, oo, mo)
+            la_o, ll_o, lat_o, g_o = orc.a_step(o, x, y, oo[1], 15.0, 0.1, 5.0, noise=na)
+            la_m, ll_m, lat_m, g_m = search.a_step(st, x.cuda(), y.cuda(), mo[1], 15.0, 0.1, 5.0, noise=na.cuda())
+            assert abs(float(lat_o) - float(lat_m)) < 1e-3
+            if it == 0:
+                for a, b in zip(g_o, g_m):
+                    assert torch.allclose(b.cpu(), a, atol=1e-4), float((b.cpu() - a).abs().max())
+            for a, b in zip(o.arch_parameters(), m.arch_parameters()):
+                assert torch.allclose(b.detach().cpu(), a.detach(), atol=tol[k]), (k, float((b.cpu() - a).abs().max()))
+    # architecture-level agreement at the end of the free run
+    for a, b in zip(o.arch_parameters(), m.arch_parameters()):
+        assert int(a.argmax()) == int(b.argmax()) or float((b.cpu() - a).abs().max()) < 5e-3

@@ -1,0 +1,98 @@
+"""CPU tests of the host-side mirror of the reference API (no GPU, no kernels)."""
+import random
+from collections import OrderedDict
+
+import pytest
+import torch
+
+import tfnas_oracle as orc
+
+
+@pytest.fixture(scope='module')
+def lut():
+    from tfnas_amd.latency import load_lat_lookup
+    return load_lat_lookup('gpu')
+
+
+@pytest.fixture(scope='module')
+def net(lut):
+    from tfnas_amd import Network, geometry
+    torch.manual_seed(2)
+    return Network(100, geometry.initial_mc_num_dddict(), lut)
+
+
+def test_parameter_names_order_and_init_match_oracle(net, lut):
+    torch.manual_seed(2)
+    o = orc.Network(100, orc.initial_mc_num_dddict(), lut)
+    a, b = net.state_dict(), o.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert [k for k, _ in net.named_parameters()] == [k for k, _ in o.named_parameters()]
+    assert len(net.arch_parameters()) == 24 and sum(p.numel() for p in net.arch_parameters()) == 162
+    assert len(net.log_alphas_parameters()) == 18 and len(net.betas_parameters()) == 6
+    keys = [k for k in a if k.endswith('log_alphas') or k.endswith('betas')]
+    assert keys[:4] == ['stage1.betas', 'stage1.block1.log_alphas', 'stage1.block2.log_alphas', 'stage2.betas']
+    assert sum(p.numel() for p in net.weight_parameters()) == 33295566 - 162
+
+
+def test_reference_attribute_paths_exist(net):
+    """the attribute paths train_search.py:164-193 reaches through exec()"""
+    op = net.stage3.block2.m_ops[5]
+    assert op.inverted_bottleneck.conv.weight.shape == (480, 80, 1, 1)
+    assert op.depth_conv.conv.weight.shape == (480, 1, 3, 3)
+    assert op.point_linear.conv.weight.shape == (80, 480, 1, 1)
+    assert op.squeeze_excite.conv_reduce.weight.shape == (160, 480, 1, 1)
+    assert op.squeeze_excite.conv_reduce.bias.shape == (160,)
+    assert op.squeeze_excite.conv_expand.weight.shape == (480, 160, 1, 1)
+    assert (op.name, op.in_channels, op.mid_channels, op.se_channels, op.out_channels, op.kernel_size, op.stride,
+            op.act_func) == ('MBInvertedResBlock', 80, 480, 160, 80, 3, 1, 'swish')
+    assert net.stage1.block1.m_ops[2].kernel_size == 5 and net.stage1.block1.m_ops[0].squeeze_excite is None
+    assert net.second_stem.inverted_bottleneck is None
+    # widths can be re-assigned through .data like the reference's epoch plumbing does
+    w = op.inverted_bottleneck.conv.weight
+    w.data = torch.index_select(w.data, 0, torch.arange(100))
+    assert op.inverted_bottleneck.conv.weight.shape[0] == 100
+
+
+def test_lookup_latency_api(net, lut):
+    blk = net.stage2.block2
+    lats = blk.get_lookup_latency(28)
+    assert lats == [lut['MBInvertedResBlock_28_40_%d_40_k%d_s1_swish' % (se, k)][mc]
+                    for se, k, mc in [(0, 3, 120), (0, 3, 240), (0, 5, 120), (0, 5, 240),
+                                      (40, 3, 120), (80, 3, 240), (40, 5, 120), (80, 5, 240)]]
+    with pytest.raises(KeyError):
+        blk.get_lookup_latency(27)
+
+
+def test_switch_bookkeeping_random_mode(net):
+    blk = net.stage1.block1
+    blk.reset_switches()
+    blk.switches[3] = False                    # as if 'gumbel' had picked op 3
+    assert blk.fink_ori_idx(3) == 4
+    random.seed(1)
+    want = blk.fink_ori_idx(random.choice(range(7)))
+    random.seed(1)
+    assert blk.sample_index('random') == want and all(blk.switches)
+    with pytest.raises(ValueError):
+        blk.sample_index('max')
+    from tfnas_amd.model_search import MixedStage
+    with pytest.raises(ValueError):
+        MixedStage([16], [24], [2], [False], ['relu'], net.mc_num_dddict['stage1'], {}, 7)
+
+
+def test_no_cpu_fallback(net):
+    with pytest.raises(RuntimeError, match='GPU'):
+        net(torch.zeros(1, 3, 224, 224), False)
+    with pytest.raises(RuntimeError, match='GPU'):
+        net.stage1.block1.m_ops[0](torch.zeros(1, 16, 8, 8))
+
+
+def test_product_package_does_not_import_oracle():
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tf-nas_amd')
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+tfnas_oracle', src, flags=re.M), f
+                assert '/root/reference' not in src, f

@@ -5,6 +5,7 @@
 //            MixedStage.forward tail (:202-204).
 #include "tfnas_dev.h"
 #include "kernels.h"
+#include "prof.h"
 
 struct PtrPack {
     const float* p[TFNAS_MAX_CELLS];
@@ -201,6 +202,7 @@ __global__ void k_sink_bwd_fin(int K, const float* __restrict__ bw, const float*
 // ============================================================================ host launchers
 int launch_arch_fwd(int ncell, const float* const* la, const float* e, const float* lat, float T, float* w,
                     float* cell_lat, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     PtrPack pk;
     for (int i = 0; i < ncell; ++i) pk.p[i] = la[i];
     hipLaunchKernelGGL(k_arch_fwd, dim3(1), dim3(64), 0, s, ncell, pk, e, lat, T, w, cell_lat);
@@ -209,6 +211,7 @@ int launch_arch_fwd(int ncell, const float* const* la, const float* e, const flo
 
 int launch_arch_bwd(int ncell, const float* w, const float* lat, const float* dw, const float* dcl, float T,
                     float* const* dla, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     MutPtrPack pk;
     for (int i = 0; i < ncell; ++i) pk.p[i] = dla[i];
     hipLaunchKernelGGL(k_arch_bwd, dim3(1), dim3(64), 0, s, ncell, w, lat, dw, dcl, T, pk);
@@ -217,6 +220,7 @@ int launch_arch_bwd(int ncell, const float* w, const float* lat, const float* dw
 
 int launch_arch_sample(int ncell, const float* const* la, const uint8_t* mask, const float* e, float T, int mode,
                        int32_t* pos, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     PtrPack pk;
     for (int i = 0; i < ncell; ++i) pk.p[i] = la[i];
     hipLaunchKernelGGL(k_arch_sample, dim3(1), dim3(64), 0, s, ncell, pk, mask, e, T, mode, pos);
@@ -232,6 +236,7 @@ static unsigned stream_blocks(uint64_t count4) {
 
 int launch_sink_fwd(int K, const float* betas, const float* const* res, const float* cell_lat, uint64_t count,
                     float* out, float* out_lat, float* bw, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     SinkPtrs pk = {};
     for (int k = 0; k < K; ++k) pk.res[k] = res[k];
     hipLaunchKernelGGL(k_sink_fwd, dim3(stream_blocks(count / 4)), dim3(256), 0, s, K, betas, pk, cell_lat,
@@ -242,6 +247,7 @@ int launch_sink_fwd(int K, const float* betas, const float* const* res, const fl
 int launch_sink_bwd(int K, const float* bw, const float* const* res, const float* cell_lat, const float* dout,
                     const float* dlat, uint64_t count, float* const* dres, float* dbetas, float* dcell_lat,
                     double* dots, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     SinkPtrs pk = {};
     for (int k = 0; k < K; ++k) {
         pk.res[k] = res[k];

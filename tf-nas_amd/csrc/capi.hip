@@ -68,7 +68,8 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_red3 = 0;
     ws->off_red2 = 2 * G * oc;
     ws->off_red1 = 2 * G * oc + 2 * M;
-    ws->red = 2 * G * oc + 4 * M;
+    ws->off_resdot = 2 * G * oc + 4 * M;
+    ws->red = ws->off_resdot + 2;
     ws->dx = P * d->ic;
     return 0;
 }
@@ -138,8 +139,8 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
             if (gr.se > 0 && (!gr.g_se_r || !gr.gb_se_r || !gr.g_se_e || !gr.gb_se_e)) return TFNAS_ENULL;
         }
     }
-    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, red3, s));           // BN3 backward sums (+ d wmix)
-    if (dwmix) TRY(launch_mix_dw(d, red3, dwmix, s));
+    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, x, red3, red + ws.off_resdot, s));           // BN3 backward sums (+ d wmix)
+    if (dwmix) TRY(launch_mix_dw(d, red3, red + ws.off_resdot, dwmix, s));
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
     if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, s));
     TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate

@@ -11,6 +11,7 @@
 // one ds_read_b128 of 4 channels and the k-wide sliding window lives in registers.
 #include "tfnas_dev.h"
 #include "kernels.h"
+#include "prof.h"
 
 struct DwGeom {
     int T0, T1;        // tile height / width (in outputs for fwd & wgrad, in inputs for bwd-data)
@@ -431,6 +432,7 @@ static int dw_chunks(const TfnasCellDesc& d, int K, int CC) {
 
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
                   hipStream_t s) {
+    ProfScope _prof(TK_DW_FWD, s);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
         pick_tile(d.Ho, d.Wo, kk, d.stride, true, gm);
@@ -450,6 +452,7 @@ int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, 
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
                        hipStream_t s) {
+    ProfScope _prof(TK_DW_BWD_DATA, s);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
         pick_tile(d.H, d.W, kk, d.stride, false, gm);
@@ -469,6 +472,7 @@ int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D,
 
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
                     const double* red2, const float* E, const double* stats1, hipStream_t s) {
+    ProfScope _prof(TK_DW_WGRAD, s);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
         pick_tile(d.Ho, d.Wo, kk, d.stride, true, gm);

@@ -6,6 +6,7 @@
 // and the autograd backward of those convolutions + BatchNorm2d(affine=False, batch stats).
 #include "gemm_core.h"
 #include "kernels.h"
+#include "prof.h"
 
 // ============================================================================ expand forward
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
@@ -451,6 +452,7 @@ static int row_blocks(int rows, int other_blocks) {
 }
 
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, hipStream_t s) {
+    ProfScope _prof(TK_EXPAND_FWD, s);
     constexpr int NT = 4;
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
@@ -461,6 +463,7 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
 
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
                        float* Pr, double* stats3, hipStream_t s) {
+    ProfScope _prof(TK_PROJECT_FWD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     int mcp_max = 0;
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
@@ -475,6 +478,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
 
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
                          const double* red3, const float* wmix, float* dZ, hipStream_t s) {
+    ProfScope _prof(TK_PROJECT_DGRAD, s);
     constexpr int NT = 4;
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
@@ -495,6 +499,7 @@ static int pick_rows_per_split(int rows, int out_tiles) {
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, hipStream_t s) {
+    ProfScope _prof(TK_PROJECT_WGRAD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     const int Po = d.N * d.Ho * d.Wo;
     int mcp_max = 0;
@@ -512,6 +517,7 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
 
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* dout, const float* wmix, float* dx, hipStream_t s) {
+    ProfScope _prof(TK_EXPAND_DGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles), tiles);
@@ -523,6 +529,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E
 
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, hipStream_t s) {
+    ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;
     int mtiles = 0;

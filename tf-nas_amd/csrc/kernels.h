@@ -32,8 +32,8 @@ int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, f
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s);
 int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         double* red3, hipStream_t s);
-int launch_mix_dw(const TfnasCellDesc& d, const double* red3, float* dwmix, hipStream_t s);
+                         const float* x, double* red3, double* resdot, hipStream_t s);
+int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resdot, float* dwmix, hipStream_t s);
 int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
                          float* dgate, hipStream_t s);
 int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,

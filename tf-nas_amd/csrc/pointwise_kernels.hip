@@ -4,6 +4,7 @@
 //   BatchNorm backward statistics passes (autograd of BatchNorm2d(affine=False) with batch statistics)
 #include "tfnas_dev.h"
 #include "kernels.h"
+#include "prof.h"
 
 // sum v over the threads of the block that share `col` (rows pr = 0..RP-1); result valid where pr == 0
 __device__ __forceinline__ f32x4 reduce_rows(f32x4 v, f32x4* buf, int pr, int col, int RP, int TQ, bool active) {
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void k_mix_fwd(TfnasCellDesc d, const float* _
 __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
-                                                       double* __restrict__ red3, int rows_per_block) {
+                                                       const float* __restrict__ x, double* __restrict__ red3,
+                                                       double* __restrict__ resdot, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int oc = d.oc, G = d.G, TQ = oc >> 2, RP = 256 / TQ;
     const int Po = d.N * d.Ho * d.Wo;
@@ -249,13 +251,14 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
     const int tid = threadIdx.x, oq = tid % TQ, pr = tid / TQ, o = 4 * oq;
     const bool active = pr < RP;
     const int p0 = blockIdx.x * rows_per_block, p1 = min(Po, p0 + rows_per_block);
-    f32x4 s1 = zero4(), s2[TFNAS_MAX_GROUPS];
+    f32x4 s1 = zero4(), sx = zero4(), s2[TFNAS_MAX_GROUPS];
 #pragma unroll
     for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) s2[g] = zero4();
     if (active) {
         for (int p = p0 + pr; p < p1; p += RP) {
             const f32x4 dv = ld4(dout + (size_t)p * oc + o);
             s1 += dv;
+            if (d.has_res) sx += dv * ld4(x + (size_t)p * d.ic + o);   // residual cells: ic == oc
 #pragma unroll
             for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
                 if (g < G) {
@@ -270,6 +273,10 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
         }
     }
     s1 = reduce_rows(s1, buf, pr, oq, RP, TQ, active);
+    if (d.has_res) {
+        sx = reduce_rows(sx, buf, pr, oq, RP, TQ, active);
+        if (active && pr == 0) atomic_add_f64(resdot, (double)((sx.x + sx.y) + (sx.z + sx.w)));
+    }
 #pragma unroll
     for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
         if (g < G) {
@@ -285,12 +292,12 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
     }
 }
 
-// dwmix[g] = <dout, phat_g> = sum_o S2[g][o]   (the residual's <dout,x> term is the same for every g and is
-// annihilated by the softmax Jacobian, so it is omitted)
-__global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, float* __restrict__ dwmix) {
+// dwmix[g] = d loss / d wmix[g] = <dout, phat_g [+ x]> = sum_o S2[g][o] [+ <dout,x>]
+__global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const double* __restrict__ resdot,
+                         float* __restrict__ dwmix) {
     const int g = threadIdx.x;
     if (g < d.G) {
-        double s = 0.0;
+        double s = d.has_res ? resdot[0] : 0.0;
         for (int o = 0; o < d.oc; ++o) s += red3[2 * ((size_t)g * d.oc + o) + 1];
         dwmix[g] = (float)s;
     }
@@ -378,6 +385,7 @@ __global__ void k_bn1_consts(TfnasCellDesc d, const double* __restrict__ stats1,
     else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
 
 int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2, float* pooled, hipStream_t s) {
+    ProfScope _prof(TK_SE_POOL, s);
     const int chunks = chunk_count(d, 64, true);
     if (!chunks) return 0;
     dim3 grid(d.N, chunks);
@@ -389,6 +397,7 @@ int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2,
 
 int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
                          float* dgate, hipStream_t s) {
+    ProfScope _prof(TK_SE_BWD_REDUCE, s);
     const int chunks = chunk_count(d, 64, true);
     if (!chunks) return 0;
     dim3 grid(d.N, chunks);
@@ -406,6 +415,7 @@ static size_t se_fc_shm(const TfnasCellDesc& d) {
 }
 
 int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s) {
+    ProfScope _prof(TK_SE_FC_FWD, s);
     const int ng = se_group_count(d);
     if (!ng) return 0;
     dim3 grid(d.N, ng);
@@ -417,6 +427,7 @@ int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, f
 
 int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
                      float* dgl, float* dhpre, float* dpooled, hipStream_t s) {
+    ProfScope _prof(TK_SE_FC_BWD, s);
     const int ng = se_group_count(d);
     if (!ng) return 0;
     dim3 grid(d.N, ng);
@@ -429,6 +440,7 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
 
 int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre, const float* hpre,
                     const float* pooled, hipStream_t s) {
+    ProfScope _prof(TK_SE_WGRAD, s);
     const int ng = se_group_count(d);
     if (!ng) return 0;
     long mx = 0;
@@ -448,6 +460,7 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre
 
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s) {
+    ProfScope _prof(TK_MIX_FWD, s);
     const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4);
     size_t blocks = cdiv64(total, 256 * 4);
     if (blocks > 4096) blocks = 4096;
@@ -458,23 +471,27 @@ int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3
 }
 
 int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         double* red3, hipStream_t s) {
+                         const float* x, double* red3, double* resdot, hipStream_t s) {
+    ProfScope _prof(TK_MIX_BWD_STATS, s);
     const int Po = d.N * d.Ho * d.Wo;
     int rpb = cdiv(Po, 1024);
     const int RP = 256 / (d.oc / 4);
     if (rpb < 8 * RP) rpb = 8 * RP;
     const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
-    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(cdiv(Po, rpb)), dim3(256), shm, s, d, dout, Pr, stats3, red3, rpb);
+    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(cdiv(Po, rpb)), dim3(256), shm, s, d, dout, Pr, stats3, x, red3, resdot,
+                       rpb);
     return (int)hipGetLastError();
 }
 
-int launch_mix_dw(const TfnasCellDesc& d, const double* red3, float* dwmix, hipStream_t s) {
-    hipLaunchKernelGGL(k_mix_dw, dim3(1), dim3(64), 0, s, d, red3, dwmix);
+int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resdot, float* dwmix, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    hipLaunchKernelGGL(k_mix_dw, dim3(1), dim3(64), 0, s, d, red3, resdot, dwmix);
     return (int)hipGetLastError();
 }
 
 int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
                    const float* dpooled, double* red2, hipStream_t s) {
+    ProfScope _prof(TK_BN2_BWD, s);
     const int Po = d.N * d.Ho * d.Wo;
     const int chunks = chunk_count(d, 64, false);
     int want = cdiv(2048, chunks);
@@ -489,6 +506,7 @@ int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const doub
 
 int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,
                       hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
     hipLaunchKernelGGL(k_bn1_consts, dim3(cdiv(d.M, 256)), dim3(256), 0, s, d, stats1, red1, cb1);
     return (int)hipGetLastError();
 }

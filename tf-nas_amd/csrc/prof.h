@@ -1,0 +1,19 @@
+// Opt-in per-kernel-family timing with HIP events on the launch stream (diagnostics for bench.py's roofline
+// line; disabled by default -> zero overhead beyond one load).  See tfnas_prof_* in include/tfnas_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum TfnasKernelId {
+    TK_EXPAND_FWD = 0, TK_DW_FWD, TK_SE_POOL, TK_SE_FC_FWD, TK_PROJECT_FWD, TK_MIX_FWD,
+    TK_MIX_BWD_STATS, TK_PROJECT_DGRAD, TK_PROJECT_WGRAD, TK_SE_BWD_REDUCE, TK_SE_FC_BWD, TK_SE_WGRAD,
+    TK_BN2_BWD, TK_DW_BWD_DATA, TK_DW_WGRAD, TK_EXPAND_DGRAD, TK_EXPAND_WGRAD, TK_SMALL, TK_COUNT
+};
+
+struct ProfScope {
+    int id;
+    hipStream_t s;
+    hipEvent_t e0;
+    bool on;
+    ProfScope(int id, hipStream_t s);
+    ~ProfScope();
+};

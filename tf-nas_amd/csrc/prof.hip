@@ -1,0 +1,53 @@
+#include <mutex>
+#include <vector>
+#include "prof.h"
+#include "tfnas_hip.h"
+
+static unsigned g_mask = 0;
+static std::mutex g_mu;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev[TK_COUNT];
+
+static const char* kNames[TK_COUNT] = {
+    "k_expand_fwd", "k_dw_fwd", "k_se_pool<fwd>", "k_se_fc_fwd", "k_project_fwd", "k_mix_fwd",
+    "k_mix_bwd_stats", "k_project_dgrad", "k_project_wgrad", "k_se_pool<bwd>", "k_se_fc_bwd", "k_se_wgrad",
+    "k_bn2_bwd", "k_dw_bwd_data", "k_dw_wgrad", "k_expand_dgrad", "k_expand_wgrad", "small(arch/sink/consts)"};
+
+ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), e0(nullptr), on(false) {
+    if (g_mask & (1u << id)) {
+        if (hipEventCreate(&e0) == hipSuccess && hipEventRecord(e0, s) == hipSuccess) on = true;
+    }
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    hipEvent_t e1;
+    if (hipEventCreate(&e1) != hipSuccess) return;
+    hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_ev[id].emplace_back(e0, e1);
+}
+
+extern "C" int tfnas_prof_enable(unsigned mask) {
+    g_mask = mask;
+    return 0;
+}
+extern "C" int tfnas_prof_count(void) { return TK_COUNT; }
+extern "C" const char* tfnas_prof_name(int id) { return (id >= 0 && id < TK_COUNT) ? kNames[id] : ""; }
+
+extern "C" int tfnas_prof_collect(int id, uint64_t* launches, double* total_ms) {
+    if (id < 0 || id >= TK_COUNT || !launches || !total_ms) return TFNAS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    *launches = 0;
+    *total_ms = 0.0;
+    for (auto& pr : g_ev[id]) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(pr.second);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+        if (e != hipSuccess) return (int)e;
+        *launches += 1;
+        *total_ms += ms;
+    }
+    g_ev[id].clear();
+    return 0;
+}

@@ -31,7 +31,7 @@ class TfnasCellWs(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         'E', 'D', 'Pr', 'fsmall', 'off_pooled', 'off_gate', 'off_hpre', 'stats', 'off_stats1', 'off_stats2',
         'off_stats3', 'out', 'dZ', 'dEh', 'bsmall', 'off_dgate', 'off_dpooled', 'off_dgl', 'off_dhpre', 'off_cb1',
-        'red', 'off_red3', 'off_red2', 'off_red1', 'dx')]
+        'red', 'off_red3', 'off_red2', 'off_red1', 'off_resdot', 'dx')]
 
 
 _P = C.c_void_p
@@ -46,6 +46,10 @@ _PROTOS = {
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),
+    'tfnas_prof_enable': (C.c_int, [C.c_uint]),
+    'tfnas_prof_count': (C.c_int, []),
+    'tfnas_prof_name': (C.c_char_p, [C.c_int]),
+    'tfnas_prof_collect': (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     'tfnas_sink_bwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, _P, _P, C.c_uint64, C.POINTER(_P), _P, _P, _P, _P]),
 }
 
