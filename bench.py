@@ -112,7 +112,7 @@ def run_gpu(args):
     pool = 4
 
     def batch():
-        return (torch.randn(B, 3, 224, 224, device=dev, generator=gen).contiguous(memory_format=torch.channels_last),
+        return (torch.randn(B, 3, 224, 224, device=dev, generator=gen),
                 torch.randint(0, 100, (B,), device=dev, generator=gen))
     train = [batch() for _ in range(2 * pool)]
     val = [batch() for _ in range(pool)]

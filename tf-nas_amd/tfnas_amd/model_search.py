@@ -264,9 +264,13 @@ class Network(nn.Module):
 
     def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None):
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
-        x = x.contiguous(memory_format=torch.channels_last)
+        # stems use stock PyTorch-ROCm ops in plain NCHW: MIOpen's fp32 NHWC path falls back to naive_conv_*
+        # kernels (368 ms per wgrad at batch 128, profiles/round1_first_kernel_stats.csv); the MixedOP cells
+        # want NHWC, so the (small, 16-channel) stem output is re-laid-out once here.
+        x = x.contiguous()
         x = self.first_stem(x)
         x = self.second_stem(x)
+        x = x.contiguous(memory_format=torch.channels_last)
         self._prepare(x, sampling, mode, exp_noise, rand_pos)
         for st in self.stages():
             x, lat = st(x, sampling, mode)
