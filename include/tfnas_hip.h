@@ -95,8 +95,10 @@ typedef struct TfnasCellWs {
     uint64_t dEh;      /* floats  [N*H*W][M]                                                */
     uint64_t bsmall;   /* floats  dgate[N][M] | dpooled[N][M] | dgl[N][M] | dhpre[N][SE] | cb1[M][4] */
     uint64_t off_dgate, off_dpooled, off_dgl, off_dhpre, off_cb1;
-    uint64_t red;      /* doubles red3[G*oc][2] | red2[M][2] | red1[M][2] | resdot[2]       */
-    uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = <dout, x> of residual cells */
+    uint64_t red;      /* doubles red3[G*oc][2] | resdot[oc] | red2[M][2] | red1[M][2]      */
+    uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = per-channel <dout, x> of residual cells */
+    uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd); reductions are done by a
+                          second tiny kernel instead of device-scope atomics -> deterministic results          */
     uint64_t dx;       /* floats  [N*H*W][ic]                                               */
 } TfnasCellWs;
 
@@ -119,16 +121,16 @@ int tfnas_cell_ws(const TfnasCellDesc *d, TfnasCellWs *ws);
  *       out = m_ops[idx](x);  replaces models/model_search.py:84-85 -> MBInvertedResBlock.forward layers.py:539-561
  * BN everywhere = batch statistics, biased variance, no affine (layers.py:469,498,533). */
 int tfnas_mixedop_fwd(const TfnasCellDesc *d, const float *x, const float *wmix,
-                      float *E, float *D, float *Pr, float *fsmall, double *stats,
+                      float *E, float *D, float *Pr, float *fsmall, double *stats, float *part,
                       float *out, void *stream);
 
 /* MixedOP backward (what autograd does for the graph above).  Produces dx [N*H*W][ic], dwmix[G]
  * (d loss / d wmix[g]; may be NULL in sampled mode) and, when d->need_wgrad, the g_* weight gradients
- * (overwritten, not accumulated).  dZ/dEh/bsmall/red are scratch. */
+ * (overwritten, not accumulated).  dZ/dEh/bsmall/red/part are scratch. */
 int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
                       const float *E, const float *D, const float *Pr, const float *fsmall,
                       const double *stats, const float *dout,
-                      float *dZ, float *dEh, float *bsmall, double *red,
+                      float *dZ, float *dEh, float *bsmall, double *red, float *part,
                       float *dx, float *dwmix, void *stream);
 
 /* Gumbel-softmax over the candidates of `ncell` cells in one launch + expected cell latency.

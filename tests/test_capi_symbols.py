@@ -81,7 +81,7 @@ def test_error_codes(lib):
     d = _desc()
     lib.tfnas_cell_plan(C.byref(d))
     # NULL buffers are rejected before any launch (no GPU needed)
-    assert lib.tfnas_mixedop_fwd(C.byref(d), None, None, None, None, None, None, None, None, None) == -2
+    assert lib.tfnas_mixedop_fwd(C.byref(d), None, None, None, None, None, None, None, None, None, None) == -2
     assert lib.tfnas_arch_fwd(0, None, None, None, 1.0, None, None, None) == -3
     assert lib.tfnas_sink_fwd(5, None, None, None, 8, None, None, None, None) == -3
 

@@ -66,10 +66,11 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_cb1 = 3 * N * M + ((N * SE + 3) & ~(uint64_t)3);
     ws->bsmall = ws->off_cb1 + 4 * M;
     ws->off_red3 = 0;
-    ws->off_red2 = 2 * G * oc;
-    ws->off_red1 = 2 * G * oc + 2 * M;
-    ws->off_resdot = 2 * G * oc + 4 * M;
-    ws->red = ws->off_resdot + 2;
+    ws->off_resdot = 2 * G * oc;                 /* [oc] per-channel <dout,x>, contiguous with red3 */
+    ws->off_red2 = 2 * G * oc + oc;
+    ws->off_red1 = ws->off_red2 + 2 * M;
+    ws->red = ws->off_red1 + 2 * M;
+    ws->part = TFNAS_PART_FLOATS;
     ws->dx = P * d->ic;
     return 0;
 }
@@ -81,8 +82,8 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     } while (0)
 
 extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const float* wmix, float* E, float* D,
-                                 float* Pr, float* fsmall, double* stats, float* out, void* stream) {
-    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !out) return TFNAS_ENULL;
+                                 float* Pr, float* fsmall, double* stats, float* part, float* out, void* stream) {
+    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
@@ -93,21 +94,20 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     float* pooled = fsmall + ws.off_pooled;
     float* gate = fsmall + ws.off_gate;
     float* hpre = fsmall + ws.off_hpre;
-    HIP_TRY(hipMemsetAsync(stats, 0, ws.stats * sizeof(double), s));
-    TRY(launch_expand_fwd(d, x, E, stats1, s));           // 1x1 expand (all groups) + BN1 statistics
-    TRY(launch_dw_fwd(d, E, stats1, D, stats2, s));       // BN1+act fused load, depthwise, BN2 statistics
+    TRY(launch_expand_fwd(d, x, E, stats1, part, s));     // 1x1 expand (all groups) + BN1 statistics
+    TRY(launch_dw_fwd(d, E, stats1, D, stats2, part, s)); // BN1+act fused load, depthwise, BN2 statistics
     TRY(launch_se_pool(d, D, stats2, pooled, s));         // SE squeeze (SE groups only)
     TRY(launch_se_fc_fwd(d, pooled, hpre, gate, s));      // SE excite
-    TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
+    TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
     TRY(launch_mix_fwd(d, Pr, stats3, wmix, x, out, s));  // sum_g w_g BN3(.) + residual
     return 0;
 }
 
 extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const float* wmix, const float* E,
                                  const float* D, const float* Pr, const float* fsmall, const double* stats,
-                                 const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* dx,
-                                 float* dwmix, void* stream) {
-    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !dx)
+                                 const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* part,
+                                 float* dx, float* dwmix, void* stream) {
+    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part || !dx)
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     TfnasCellWs ws;
@@ -128,30 +128,26 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     double* red2 = red + ws.off_red2;
     double* red1 = red + ws.off_red1;
 
-    HIP_TRY(hipMemsetAsync(red, 0, ws.red * sizeof(double), s));
     if (d.need_wgrad) {
         for (int g = 0; g < d.G; ++g) {
             const TfnasGroup& gr = d.g[g];
             if (!gr.g_expand || !gr.g_dw || !gr.g_proj) return TFNAS_ENULL;
-            HIP_TRY(hipMemsetAsync(gr.g_expand, 0, sizeof(float) * (size_t)gr.mc * d.ic, s));
-            HIP_TRY(hipMemsetAsync(gr.g_dw, 0, sizeof(float) * (size_t)gr.mc * gr.k * gr.k, s));
-            HIP_TRY(hipMemsetAsync(gr.g_proj, 0, sizeof(float) * (size_t)gr.mc * d.oc, s));
             if (gr.se > 0 && (!gr.g_se_r || !gr.gb_se_r || !gr.g_se_e || !gr.gb_se_e)) return TFNAS_ENULL;
         }
     }
-    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, x, red3, red + ws.off_resdot, s));           // BN3 backward sums (+ d wmix)
+    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, x, red3, part, s));           // BN3 backward sums (+ d wmix)
     if (dwmix) TRY(launch_mix_dw(d, red3, red + ws.off_resdot, dwmix, s));
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
-    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, s));
+    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part, s));
     TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
-    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgl, dhpre, hpre, pooled, s));
-    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, s));     // dZ <- d dhat ; BN2 backward sums
-    TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, s));   // depthwise dgrad + BN1 bwd sums
-    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, s));
+    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, s));
+    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));     // dZ <- d dhat ; BN2 backward sums
+    TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
+    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, s));       // dx = de W_expand (+ residual)
-    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, s));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }
 

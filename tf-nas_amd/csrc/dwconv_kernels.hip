@@ -6,9 +6,12 @@
 // zero padding applied after it, exactly like conv padding of the activated tensor); the BN2 batch
 // statistics of the conv output are accumulated in the epilogue.
 //
-// Work decomposition: one workgroup = one spatial tile x one chunk of CC channels of one group.
-// Threads are (channel-quad, strip) pairs; a strip is 4 consecutive pixels along W, so every LDS access is
-// one ds_read_b128 of 4 channels and the k-wide sliding window lives in registers.
+// Work decomposition: a workgroup owns one chunk of CC channels of one group and walks over spatial tiles
+// (persistent, grid-stride): the depthwise weights and BN constants of the chunk are staged in LDS once, the
+// per-channel statistics are accumulated in registers across tiles and flushed with ONE set of double atomics
+// per workgroup.  Threads are (channel-quad, strip) pairs; a strip is 4 consecutive pixels along W, so every
+// LDS access is one ds_read_b128 of 4 channels and the k-wide sliding window lives in registers.  Tile loads
+// are issued 4 at a time per thread before any of them is consumed (memory-level parallelism).
 #include "tfnas_dev.h"
 #include "kernels.h"
 #include "prof.h"
@@ -16,7 +19,9 @@
 struct DwGeom {
     int T0, T1;        // tile height / width (in outputs for fwd & wgrad, in inputs for bwd-data)
     int CC;            // channels per workgroup (16/32/64)
-    int tilesH, tilesW;
+    int cq_shift;      // log2(CC/4)
+    int tilesH, tilesW, ntiles;   // ntiles = N * tilesH * tilesW
+    int L0, L1;        // LDS tile extent (rows, cols)
 };
 
 __device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
@@ -36,43 +41,78 @@ __device__ __forceinline__ bool dw_locate(const TfnasCellDesc& d, int cy, int CC
     return false;
 }
 
-// sum the per-thread float4 partials of all threads that share a channel quad (tid % CQ) and add the
-// CC per-channel totals to the double accumulators acc[2*(c)+which]
-__device__ __forceinline__ void dw_flush_pair(f32x4 a, f32x4 b, float* red, int CC, int c0, int mc, double* acc) {
+// sum the per-thread float4 partials of all threads that share a channel quad (tid % CQ) and store the CC
+// per-channel totals as this workgroup's partial pair: acc[2*c + which] (acc = row blockIdx.x of the partials
+// matrix, already offset to the group's first channel); k_reduce_rows sums the rows afterwards
+__device__ __forceinline__ void dw_flush_pair(f32x4 a, f32x4 b, float* red, int CC, int c0, int mcp, float* acc) {
     const int tid = threadIdx.x, CQ = CC >> 2;
     __syncthreads();
     st4(red + tid * 8, a);
     st4(red + tid * 8 + 4, b);
     __syncthreads();
-    if (tid < CC && c0 + tid < mc) {
+    if (tid < CC && c0 + tid < mcp) {
         const int cq = tid >> 2, comp = tid & 3;
         float s = 0.f, q = 0.f;
         for (int t = cq; t < 256; t += CQ) {
             s += red[t * 8 + comp];
             q += red[t * 8 + 4 + comp];
         }
-        atomic_add_f64(acc + 2 * (size_t)(c0 + tid) + 0, (double)s);
-        atomic_add_f64(acc + 2 * (size_t)(c0 + tid) + 1, (double)q);
+        acc[2 * (size_t)(c0 + tid) + 0] = s;
+        acc[2 * (size_t)(c0 + tid) + 1] = q;
+    }
+}
+
+__device__ __forceinline__ void stage_weights(float* wts, const float* __restrict__ w, int KK, int CC, int c0, int mc) {
+    for (int idx = threadIdx.x; idx < KK * CC; idx += 256) {
+        const int cl = idx % CC, t = idx / CC;
+        wts[t * CC + cl] = (c0 + cl < mc) ? w[(size_t)(c0 + cl) * KK + t] : 0.f;
+    }
+}
+
+// Cooperative load of an [L0 x L1] pixel tile x CC channels into LDS (layout [pix][CC]).
+// fetch(pix_row, pix_col, cq, ok) -> f32x4 is called only to build the value AFTER the raw loads were issued:
+//   addr(r, c, cq, valid&) returns the element offset; xf(v, cq) transforms the loaded vector.
+template <class FAddr, class FXf>
+__device__ __forceinline__ void load_tile(float* tile, int L0, int L1, int CC, int cq_shift, const float* __restrict__ src,
+                                          FAddr addr, FXf xf) {
+    const int CQ = CC >> 2, total = L0 * L1 * CQ;
+    const float inv_l1 = 1.f / (float)L1;
+    for (int base = 0; base < total; base += 1024) {
+        f32x4 v[4];
+        int pix[4], cqv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            pix[u] = idx >> cq_shift;
+            cqv[u] = idx & (CQ - 1);
+            const int r = (int)(((float)pix[u] + 0.5f) * inv_l1);
+            const int c = pix[u] - r * L1;
+            size_t a = 0;
+            ok[u] = idx < total && addr(r, c, cqv[u], a);
+            v[u] = ok[u] ? ld4(src + a) : zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            if (idx < total) st4(tile + pix[u] * CC + 4 * cqv[u], ok[u] ? xf(v[u], cqv[u]) : zero4());
+        }
     }
 }
 
 // ============================================================================ forward
 template <int K, int S, int ACT>
-__global__ __launch_bounds__(256) void k_dw_fwd(TfnasCellDesc d, const float* __restrict__ E,
-                                                const double* __restrict__ stats1, float* __restrict__ D,
-                                                double* __restrict__ stats2, DwGeom gm) {
+__global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float* __restrict__ E,
+                                                   const double* __restrict__ stats1, float* __restrict__ D,
+                                                   float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int g, c0;
     if (!dw_locate<K>(d, blockIdx.y, gm.CC, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
-    const float* __restrict__ w = d.g[g].w_dw;
     const int CC = gm.CC, CQ = CC >> 2, TH = gm.T0, TW = gm.T1;
     const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, M = d.M;
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x, tw = bx % gm.tilesW, th = (bx / gm.tilesW) % gm.tilesH, n = bx / (gm.tilesW * gm.tilesH);
-    const int ho0 = th * TH, wo0 = tw * TW;
-    const int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-    const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
+    const int IH = gm.L0, IW = gm.L1;
 
     const int tile_floats = max(IH * IW * CC, 2048);
     float* in_tile = lds;
@@ -82,61 +122,64 @@ __global__ __launch_bounds__(256) void k_dw_fwd(TfnasCellDesc d, const float* __
     if (tid < CC)
         cst[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                    : make_float2(0.f, 0.f);
-    for (int idx = tid; idx < K * K * CC; idx += 256) {
-        const int cl = idx % CC, t = idx / CC;
-        wts[t * CC + cl] = (c0 + cl < mc) ? w[(size_t)(c0 + cl) * (K * K) + t] : 0.f;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < IH * IW * CQ; idx += 256) {
-        const int cq = idx % CQ, pix = idx / CQ;
-        const int hi = hi0 + pix / IW, wi = wi0 + pix % IW;
-        f32x4 v = zero4();
-        if (hi >= 0 && hi < H && wi >= 0 && wi < W && c0 + 4 * cq < mcp) {
-            v = ld4(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 c = cst[4 * cq + j];
-                v[j] = act_f<ACT>((v[j] - c.x) * c.y);
-            }
-        }
-        st4(in_tile + pix * CC + 4 * cq, v);
-    }
-    __syncthreads();
+    stage_weights(wts, d.g[g].w_dw, K * K, CC, c0, mc);
 
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
     f32x4 ssum = zero4(), ssq = zero4();
-    for (int item = tid; item < nstrips * CQ; item += 256) {
-        const int cq = item % CQ, st = item / CQ;
-        const int oh = st / nsw, ow0 = (st % nsw) * 4;
-        f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+        const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
+        const int ho0 = th * TH, wo0 = tw * TW;
+        const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
+        __syncthreads();     // previous tile fully consumed (and cst/wts visible on the first pass)
+        load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
+                  [&](int r, int c, int cq, size_t& a) {
+                      const int hi = hi0 + r, wi = wi0 + c;
+                      a = ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq;
+                      return hi >= 0 && hi < H && wi >= 0 && wi < W && c0 + 4 * cq < mcp;
+                  },
+                  [&](f32x4 v, int cq) {
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const float* rowp = in_tile + ((oh * S + ky) * IW + ow0 * S) * CC + 4 * cq;
-            f32x4 win[WIN];
+                      for (int j = 0; j < 4; ++j) {
+                          const float2 c = cst[4 * cq + j];
+                          v[j] = act_f<ACT>((v[j] - c.x) * c.y);
+                      }
+                      return v;
+                  });
+        __syncthreads();
+        for (int item = tid; item < nstrips * CQ; item += 256) {
+            const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
+            const int oh = st / nsw, ow0 = (st - oh * nsw) * 4;
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                const float* rowp = in_tile + ((oh * S + ky) * IW + ow0 * S) * CC + 4 * cq;
+                const float* wp = wts + ky * K * CC + 4 * cq;
+                f32x4 win[WIN];
 #pragma unroll
-            for (int t = 0; t < WIN; ++t) win[t] = ld4(rowp + t * CC);
+                for (int u = 0; u < WIN; ++u) win[u] = ld4(rowp + u * CC);
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const f32x4 wv = ld4(wts + (ky * K + kx) * CC + 4 * cq);
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 wv = ld4(wp + kx * CC);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += win[j * S + kx] * wv;
+                    for (int j = 0; j < 4; ++j) acc[j] += win[j * S + kx] * wv;
+                }
             }
-        }
-        const int ho = ho0 + oh;
-        if (ho < Ho && c0 + 4 * cq < mcp) {
+            const int ho = ho0 + oh;
+            if (ho < Ho && c0 + 4 * cq < mcp) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int wo = wo0 + ow0 + j;
-                if (wo < Wo) {
-                    st4(D + ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq, acc[j]);
-                    ssum += acc[j];
-                    ssq += acc[j] * acc[j];
+                for (int j = 0; j < 4; ++j) {
+                    const int wo = wo0 + ow0 + j;
+                    if (wo < Wo) {
+                        st4(D + ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq, acc[j]);
+                        ssum += acc[j];
+                        ssq += acc[j] * acc[j];
+                    }
                 }
             }
         }
     }
-    dw_flush_pair(ssum, ssq, in_tile, CC, c0, mc, stats2 + 2 * (size_t)off);
+    dw_flush_pair(ssum, ssq, in_tile, CC, c0, mcp, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off);
 }
 
 // ---------------------------------------------------------------------------- BN2-backward operand
@@ -173,24 +216,20 @@ __device__ __forceinline__ void fill_cst2(f32x4* cst2, const TfnasCellDesc& d, i
 // dA1[n][hi][wi][c] = sum_{ky,kx} dd[n][(hi+p-ky)/S][(wi+p-kx)/S][c] * w[c][ky][kx]   (only exact divisions)
 // epilogue: deh = dA1 * act'(ehat) -> dEh, and the BN1-backward sums (T1 = sum deh, T2 = sum deh*ehat)
 template <int K, int S, int ACT>
-__global__ __launch_bounds__(256) void k_dw_bwd_data(TfnasCellDesc d, const float* __restrict__ ddh,
-                                                     const float* __restrict__ D, const double* __restrict__ stats2,
-                                                     const double* __restrict__ red2, const float* __restrict__ E,
-                                                     const double* __restrict__ stats1, float* __restrict__ dEh,
-                                                     double* __restrict__ red1, DwGeom gm) {
+__global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const float* __restrict__ ddh,
+                                                        const float* __restrict__ D, const double* __restrict__ stats2,
+                                                        const double* __restrict__ red2, const float* __restrict__ E,
+                                                        const double* __restrict__ stats1, float* __restrict__ dEh,
+                                                        float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int g, c0;
     if (!dw_locate<K>(d, blockIdx.y, gm.CC, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
-    const float* __restrict__ w = d.g[g].w_dw;
     const int CC = gm.CC, CQ = CC >> 2, TIH = gm.T0, TIW = gm.T1;
     const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, M = d.M;
     constexpr int PAD = K / 2;
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x, tw = bx % gm.tilesW, th = (bx / gm.tilesW) % gm.tilesH, n = bx / (gm.tilesW * gm.tilesH);
-    const int hi0 = th * TIH, wi0 = tw * TIW;
-    const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
-    const int OH = (hi0 + TIH - 1 + PAD) / S - oh0 + 1, OW = (wi0 + TIW - 1 + PAD) / S - ow0 + 1;
+    const int OH = gm.L0, OW = gm.L1;      // LDS tile extent (host: worst case over tile origins)
 
     const int tile_floats = max(OH * OW * CC, 2048);
     float* dd_tile = lds;
@@ -202,108 +241,140 @@ __global__ __launch_bounds__(256) void k_dw_bwd_data(TfnasCellDesc d, const floa
     if (tid < CC)
         cst1[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                     : make_float2(0.f, 0.f);
-    for (int idx = tid; idx < K * K * CC; idx += 256) {
-        const int cl = idx % CC, t = idx / CC;
-        wts[t * CC + cl] = (c0 + cl < mc) ? w[(size_t)(c0 + cl) * (K * K) + t] : 0.f;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < OH * OW * CQ; idx += 256) {
-        const int cq = idx % CQ, pix = idx / CQ;
-        const int ho = oh0 + pix / OW, wo = ow0 + pix % OW;
-        f32x4 v = zero4();
-        if (ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp) {
-            const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-            v = bn2_dd(cst2, 4 * cq, ld4(ddh + a), ld4(D + a));
-        }
-        st4(dd_tile + pix * CC + 4 * cq, v);
-    }
-    __syncthreads();
+    stage_weights(wts, d.g[g].w_dw, K * K, CC, c0, mc);
 
     const int nsw = TIW >> 2, nstrips = TIH * nsw;
     f32x4 t1 = zero4(), t2 = zero4();
-    for (int item = tid; item < nstrips * CQ; item += 256) {
-        const int cq = item % CQ, st = item / CQ;
-        const int ih = st / nsw, iw0 = (st % nsw) * 4;
-        const int hi = hi0 + ih;
-        f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-        if (S == 1) {
-            // column index of output (wi + PAD - kx) relative to ow0 = wi0 + PAD - (K-1):  iw0 + j - kx + K - 1
+    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+        const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
+        const int hi0 = th * TIH, wi0 = tw * TIW;
+        const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
+        __syncthreads();
+        load_tile(dd_tile, OH, OW, CC, gm.cq_shift, ddh,
+                  [&](int r, int c, int cq, size_t& a) {
+                      const int ho = oh0 + r, wo = ow0 + c;
+                      a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
+                      return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
+                  },
+                  [&](f32x4 v, int cq) { return v; });
+        // second operand of the BN2-backward transform: D at the same positions (read-modify the LDS tile)
+        __syncthreads();
+        {
+            const int total = OH * OW * CQ;
+            const float inv_l1 = 1.f / (float)OW;
+            for (int base = 0; base < total; base += 1024) {
+                f32x4 v[4];
+                int pix[4], cqv[4];
+                bool ok[4];
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int r = hi + PAD - ky - oh0;
-                const float* rowp = dd_tile + (r * OW + iw0) * CC + 4 * cq;
-                f32x4 win[K + 3];
-#pragma unroll
-                for (int t = 0; t < K + 3; ++t) win[t] = ld4(rowp + t * CC);
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const f32x4 wv = ld4(wts + (ky * K + kx) * CC + 4 * cq);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] += win[j - kx + K - 1] * wv;
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    pix[u] = idx >> gm.cq_shift;
+                    cqv[u] = idx & (CQ - 1);
+                    const int r = (int)(((float)pix[u] + 0.5f) * inv_l1);
+                    const int c = pix[u] - r * OW;
+                    const int ho = oh0 + r, wo = ow0 + c;
+                    ok[u] = idx < total && ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cqv[u] < mcp;
+                    v[u] = ok[u] ? ld4(D + ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cqv[u]) : zero4();
                 }
-            }
-        } else {
-            const int base = wi0 + iw0;   // multiple of 4 -> even
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int t = hi + PAD - ky;
-                if (t & 1) continue;
-                const int r = t / 2 - oh0;   // t even: exact also for negatives
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const f32x4 wv = ld4(wts + (ky * K + kx) * CC + 4 * cq);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if ((j + PAD - kx) & 1) continue;   // compile-time after unrolling
-                        const int c = base / 2 + (j + PAD - kx) / 2 - ow0;
-                        acc[j] += ld4(dd_tile + (r * OW + c) * CC + 4 * cq) * wv;
+                for (int u = 0; u < 4; ++u) {
+                    if (ok[u]) {
+                        float* p = dd_tile + pix[u] * CC + 4 * cqv[u];
+                        st4(p, bn2_dd(cst2, 4 * cqv[u], ld4(p), v[u]));
                     }
                 }
             }
         }
-        if (hi < H && c0 + 4 * cq < mcp) {
+        __syncthreads();
+
+        for (int item = tid; item < nstrips * CQ; item += 256) {
+            const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
+            const int ih = st / nsw, iw0 = (st - ih * nsw) * 4;
+            const int hi = hi0 + ih;
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+            if (S == 1) {
+                // column of output (wi + PAD - kx) relative to ow0 = wi0 + PAD - (K-1):  iw0 + j - kx + K - 1
+#pragma unroll 1
+                for (int ky = 0; ky < K; ++ky) {
+                    const int r = hi + PAD - ky - oh0;
+                    const float* rowp = dd_tile + (r * OW + iw0) * CC + 4 * cq;
+                    const float* wp = wts + ky * K * CC + 4 * cq;
+                    f32x4 win[K + 3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int wi = wi0 + iw0 + j;
-                if (wi < W) {
-                    const size_t a = ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq;
-                    const f32x4 e = ld4(E + a);
-                    f32x4 deh;
+                    for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * CC);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float2 c = cst1[4 * cq + q];
-                        const float eh = (e[q] - c.x) * c.y;
-                        deh[q] = acc[j][q] * act_d<ACT>(eh);
-                        t1[q] += deh[q];
-                        t2[q] += deh[q] * eh;
+                    for (int kx = 0; kx < K; ++kx) {
+                        const f32x4 wv = ld4(wp + kx * CC);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] += win[j - kx + K - 1] * wv;
                     }
-                    st4(dEh + a, deh);
+                }
+            } else {
+                const int base = wi0 + iw0;   // multiple of 4 -> even
+#pragma unroll 1
+                for (int ky = 0; ky < K; ++ky) {
+                    const int tt = hi + PAD - ky;
+                    if (tt & 1) continue;
+                    const int r = tt / 2 - oh0;   // tt even: exact also for negatives
+                    const float* wp = wts + ky * K * CC + 4 * cq;
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const f32x4 wv = ld4(wp + kx * CC);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if ((j + PAD - kx) & 1) continue;   // compile-time after unrolling
+                            const int c = base / 2 + (j + PAD - kx) / 2 - ow0;
+                            acc[j] += ld4(dd_tile + (r * OW + c) * CC + 4 * cq) * wv;
+                        }
+                    }
+                }
+            }
+            if (hi < H && c0 + 4 * cq < mcp) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int wi = wi0 + iw0 + j;
+                    if (wi < W) {
+                        const size_t a = ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq;
+                        const f32x4 e = ld4(E + a);
+                        f32x4 deh;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float2 c = cst1[4 * cq + q];
+                            const float eh = (e[q] - c.x) * c.y;
+                            deh[q] = acc[j][q] * act_d<ACT>(eh);
+                            t1[q] += deh[q];
+                            t2[q] += deh[q] * eh;
+                        }
+                        st4(dEh + a, deh);
+                    }
                 }
             }
         }
     }
-    dw_flush_pair(t1, t2, dd_tile, CC, c0, mc, red1 + 2 * (size_t)off);
+    dw_flush_pair(t1, t2, dd_tile, CC, c0, mcp, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off);
 }
 
 // ============================================================================ weight gradient
-// g_dw[c][ky][kx] += sum_{n,ho,wo} dd[n][ho][wo][c] * a1[n][ho*S+ky-p][wo*S+kx-p][c],  a1 = act(BN1(E))
+// part[bx][poff_g + c*K*K + ky*K + kx] = sum over this workgroup's tiles of dd[n][ho][wo][c] * a1[n][ho*S+ky-p][wo*S+kx-p][c]
+// (a1 = act(BN1(E))); k_reduce_rows sums the workgroups into g_dw
 template <int K, int S, int ACT>
-__global__ __launch_bounds__(256) void k_dw_wgrad(TfnasCellDesc d, const float* __restrict__ ddh,
-                                                  const float* __restrict__ D, const double* __restrict__ stats2,
-                                                  const double* __restrict__ red2, const float* __restrict__ E,
-                                                  const double* __restrict__ stats1, DwGeom gm) {
+__global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const float* __restrict__ ddh,
+                                                     const float* __restrict__ D, const double* __restrict__ stats2,
+                                                     const double* __restrict__ red2, const float* __restrict__ E,
+                                                     const double* __restrict__ stats1, float* __restrict__ part,
+                                                     size_t out_size, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int g, c0;
     if (!dw_locate<K>(d, blockIdx.y, gm.CC, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
-    float* __restrict__ gw = d.g[g].g_dw;
+    size_t poff = 0;
+    for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * d.g[gg].k * d.g[gg].k;
+    float* __restrict__ gw = part + (size_t)blockIdx.x * out_size + poff;
     const int CC = gm.CC, CQ = CC >> 2, TH = gm.T0, TW = gm.T1;
     const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, M = d.M;
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x, tw = bx % gm.tilesW, th = (bx / gm.tilesW) % gm.tilesH, n = bx / (gm.tilesW * gm.tilesH);
-    const int ho0 = th * TH, wo0 = tw * TW;
-    const int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-    const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
+    const int IH = gm.L0, IW = gm.L1;
 
     const int tile_floats = max(IH * IW * CC, 4 * K * K * CC);
     float* in_tile = lds;
@@ -314,60 +385,67 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(TfnasCellDesc d, const float* 
     if (tid < CC)
         cst1[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                     : make_float2(0.f, 0.f);
-    __syncthreads();
-    for (int idx = tid; idx < IH * IW * CQ; idx += 256) {
-        const int cq = idx % CQ, pix = idx / CQ;
-        const int hi = hi0 + pix / IW, wi = wi0 + pix % IW;
-        f32x4 v = zero4();
-        if (hi >= 0 && hi < H && wi >= 0 && wi < W && c0 + 4 * cq < mcp) {
-            v = ld4(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 c = cst1[4 * cq + j];
-                v[j] = act_f<ACT>((v[j] - c.x) * c.y);
-            }
-        }
-        st4(in_tile + pix * CC + 4 * cq, v);
-    }
-    __syncthreads();
 
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
     f32x4 wacc[K * K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) wacc[t] = zero4();
-    for (int item = tid; item < nstrips * CQ; item += 256) {
-        const int cq = item % CQ, st = item / CQ;
-        const int oh = st / nsw, ow0 = (st % nsw) * 4;
-        const int ho = ho0 + oh;
-        f32x4 dd[4];
+    for (int u = 0; u < K * K; ++u) wacc[u] = zero4();
+    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+        const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
+        const int ho0 = th * TH, wo0 = tw * TW;
+        const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
+        __syncthreads();
+        load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
+                  [&](int r, int c, int cq, size_t& a) {
+                      const int hi = hi0 + r, wi = wi0 + c;
+                      a = ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq;
+                      return hi >= 0 && hi < H && wi >= 0 && wi < W && c0 + 4 * cq < mcp;
+                  },
+                  [&](f32x4 v, int cq) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int wo = wo0 + ow0 + j;
-            dd[j] = zero4();
-            if (ho < Ho && wo < Wo && c0 + 4 * cq < mcp) {
+                      for (int j = 0; j < 4; ++j) {
+                          const float2 c = cst1[4 * cq + j];
+                          v[j] = act_f<ACT>((v[j] - c.x) * c.y);
+                      }
+                      return v;
+                  });
+        __syncthreads();
+        for (int item = tid; item < nstrips * CQ; item += 256) {
+            const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
+            const int oh = st / nsw, ow0 = (st - oh * nsw) * 4;
+            const int ho = ho0 + oh;
+            f32x4 dd[4], dv[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wo = wo0 + ow0 + j;
+                ok[j] = ho < Ho && wo < Wo && c0 + 4 * cq < mcp;
                 const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-                dd[j] = bn2_dd(cst2, 4 * cq, ld4(ddh + a), ld4(D + a));
+                dd[j] = ok[j] ? ld4(ddh + a) : zero4();
+                dv[j] = ok[j] ? ld4(D + a) : zero4();
             }
-        }
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const float* rowp = in_tile + ((oh * S + ky) * IW + ow0 * S) * CC + 4 * cq;
-            f32x4 win[WIN];
+            for (int j = 0; j < 4; ++j) dd[j] = ok[j] ? bn2_dd(cst2, 4 * cq, dd[j], dv[j]) : zero4();
 #pragma unroll
-            for (int t = 0; t < WIN; ++t) win[t] = ld4(rowp + t * CC);
+            for (int ky = 0; ky < K; ++ky) {
+                const float* rowp = in_tile + ((oh * S + ky) * IW + ow0 * S) * CC + 4 * cq;
+                f32x4 win[WIN];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx)
+                for (int u = 0; u < WIN; ++u) win[u] = ld4(rowp + u * CC);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wacc[ky * K + kx] += dd[j] * win[j * S + kx];
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wacc[ky * K + kx] += dd[j] * win[j * S + kx];
+            }
         }
     }
     // reduce over the threads sharing a channel quad: first inside the wave, then across the 4 waves
     for (int o = CQ; o < 64; o <<= 1) {
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) {
+        for (int u = 0; u < K * K; ++u) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wacc[t][q] += __shfl_xor(wacc[t][q], o, 64);
+            for (int q = 0; q < 4; ++q) wacc[u][q] += __shfl_xor(wacc[u][q], o, 64);
         }
     }
     __syncthreads();
@@ -375,42 +453,44 @@ __global__ __launch_bounds__(256) void k_dw_wgrad(TfnasCellDesc d, const float* 
     const int lane = tid & 63, wv = tid >> 6;
     if (lane < CQ) {
 #pragma unroll
-        for (int t = 0; t < K * K; ++t) st4(wred + (wv * K * K + t) * CC + 4 * lane, wacc[t]);
+        for (int u = 0; u < K * K; ++u) st4(wred + (wv * K * K + u) * CC + 4 * lane, wacc[u]);
     }
     __syncthreads();
     for (int idx = tid; idx < K * K * CC; idx += 256) {
-        const int cl = idx % CC, t = idx / CC;
+        const int cl = idx % CC, u = idx / CC;
         if (c0 + cl < mc) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += wred[(ww * K * K + t) * CC + cl];
-            atomic_add_f32(gw + (size_t)(c0 + cl) * (K * K) + t, s);
+            for (int ww = 0; ww < 4; ++ww) s += wred[(ww * K * K + u) * CC + cl];
+            gw[(size_t)(c0 + cl) * (K * K) + u] = s;
         }
     }
 }
 
 // ============================================================================ host side
-static void pick_tile(int Th, int Tw, int K, int S, bool fwd_like, DwGeom& gm) {
-    // T1 (width) multiple of 4 (strips), up to 16; T0 so that a tile has ~128 pixels
+static void pick_tile(int N, int Th, int Tw, int K, int S, bool fwd_like, DwGeom& gm) {
+    // T1 (width) multiple of 4 (strips), up to 16; T0 so that a tile has ~128 (64 for stride 2) pixels
     gm.T1 = Tw >= 16 ? 16 : ((Tw + 3) / 4) * 4;
-    gm.T0 = 128 / gm.T1;
+    const int target = (S == 2 && fwd_like) ? 64 : 128;
+    gm.T0 = target / gm.T1;
     if (gm.T0 > Th) gm.T0 = Th;
     if (gm.T0 < 1) gm.T0 = 1;
     gm.tilesH = cdiv(Th, gm.T0);
     gm.tilesW = cdiv(Tw, gm.T1);
-    int lh, lw;   // LDS tile extent
+    gm.ntiles = N * gm.tilesH * gm.tilesW;
     if (fwd_like) {
-        lh = (gm.T0 - 1) * S + K;
-        lw = (gm.T1 - 1) * S + K;
+        gm.L0 = (gm.T0 - 1) * S + K;
+        gm.L1 = (gm.T1 - 1) * S + K;
     } else {
-        lh = (gm.T0 + K - 1 + S - 1) / S + 1;
-        lw = (gm.T1 + K - 1 + S - 1) / S + 1;
+        gm.L0 = (gm.T0 + K - 2) / S + 2;      // worst case over tile origins of floor((a+T+K-2)/S)-floor(a/S)+1
+        gm.L1 = (gm.T1 + K - 2) / S + 2;
     }
-    const int px = lh * lw;
+    const int px = gm.L0 * gm.L1;
     const int items32 = gm.T0 * (gm.T1 / 4) * 8;
     gm.CC = 32;
     if (px * 32 * 4 > 56 * 1024) gm.CC = 16;
-    else if (items32 < 256 && px * 64 * 4 <= 56 * 1024) gm.CC = 64;
+    else if (items32 < 192 && px * 64 * 4 <= 40 * 1024) gm.CC = 64;
+    gm.cq_shift = gm.CC == 16 ? 2 : gm.CC == 32 ? 3 : 4;
 }
 
 static int dw_chunks(const TfnasCellDesc& d, int K, int CC) {
@@ -418,6 +498,12 @@ static int dw_chunks(const TfnasCellDesc& d, int K, int CC) {
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].k == K) t += cdiv(d.g[g].mcp, CC);
     return t;
+}
+
+static int dw_grid_x(const DwGeom& gm, int chunks, int target_blocks) {
+    int gx = cdiv(target_blocks, chunks);
+    if (gx > gm.ntiles) gx = gm.ntiles;
+    return gx < 1 ? 1 : gx;
 }
 
 #define DW_DISPATCH(K_, S_, ACT_, ...)                                                         \
@@ -430,63 +516,88 @@ static int dw_chunks(const TfnasCellDesc& d, int K, int CC) {
     else if ((K_) == 5 && (S_) == 2 && (ACT_) == 0) { constexpr int K = 5, S = 2, ACT = 0; __VA_ARGS__; } \
     else { constexpr int K = 5, S = 2, ACT = 1; __VA_ARGS__; }
 
-int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
-                  hipStream_t s) {
-    ProfScope _prof(TK_DW_FWD, s);
+// Both kernel-size passes of one stage share grid.x so that they fill the same rows of the partials matrix.
+static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, int target_blocks, size_t row_floats) {
+    int gx = 1 << 30;
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.Ho, d.Wo, kk, d.stride, true, gm);
+        pick_tile(d.N, Th, Tw, kk, d.stride, fwd_like, gm);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
-        const int IH = (gm.T0 - 1) * d.stride + kk, IW = (gm.T1 - 1) * d.stride + kk;
-        const int tile = IH * IW * gm.CC > 2048 ? IH * IW * gm.CC : 2048;
+        const int g1 = dw_grid_x(gm, chunks, target_blocks);
+        if (g1 < gx) gx = g1;
+    }
+    const size_t cap = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
+    if ((size_t)gx > cap) gx = (int)cap;
+    return gx < 1 ? 1 : gx;
+}
+
+int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
+                  float* part, hipStream_t s) {
+    ProfScope _prof(TK_DW_FWD, s);
+    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M);
+    for (int kk = 3; kk <= 5; kk += 2) {
+        DwGeom gm;
+        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm);
+        const int chunks = dw_chunks(d, kk, gm.CC);
+        if (!chunks) continue;
+        const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 2 * gm.CC) * sizeof(float);
-        dim3 grid(d.N * gm.tilesH * gm.tilesW, chunks);
+        dim3 grid(gx, chunks);
         DW_DISPATCH(kk, d.stride, d.act, {
-            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT>), grid, dim3(256), shm, s, d, E, stats1, D, stats2, gm);
+            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT>), grid, dim3(256), shm, s, d, E, stats1, D, part, gm);
         })
     }
-    return (int)hipGetLastError();
+    return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
-                       hipStream_t s) {
+                       float* part, hipStream_t s) {
     ProfScope _prof(TK_DW_BWD_DATA, s);
+    const int gx = dw_common_gx(d, d.H, d.W, false, 4096, 2 * (size_t)d.M);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.H, d.W, kk, d.stride, false, gm);
+        pick_tile(d.N, d.H, d.W, kk, d.stride, false, gm);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
-        const int OH = (gm.T0 + kk - 1 + d.stride - 1) / d.stride + 1, OW = (gm.T1 + kk - 1 + d.stride - 1) / d.stride + 1;
-        const int tile = OH * OW * gm.CC > 2048 ? OH * OW * gm.CC : 2048;
+        const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
-        dim3 grid(d.N * gm.tilesH * gm.tilesW, chunks);
+        dim3 grid(gx, chunks);
         DW_DISPATCH(kk, d.stride, d.act, {
             hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT>), grid, dim3(256), shm, s, d, ddh, D, stats2, red2, E,
-                               stats1, dEh, red1, gm);
+                               stats1, dEh, part, gm);
         })
     }
-    return (int)hipGetLastError();
+    return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
-                    const double* red2, const float* E, const double* stats1, hipStream_t s) {
+                    const double* red2, const float* E, const double* stats1, float* part, hipStream_t s) {
     ProfScope _prof(TK_DW_WGRAD, s);
+    size_t out_size = 0;
+    for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.g[g].k * d.g[g].k;
+    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 2048, out_size);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.Ho, d.Wo, kk, d.stride, true, gm);
+        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
-        const int IH = (gm.T0 - 1) * d.stride + kk, IW = (gm.T1 - 1) * d.stride + kk;
-        int tile = IH * IW * gm.CC;
+        int tile = gm.L0 * gm.L1 * gm.CC;
         if (tile < 4 * kk * kk * gm.CC) tile = 4 * kk * kk * gm.CC;
         const size_t shm = (size_t)(tile + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
-        dim3 grid(d.N * gm.tilesH * gm.tilesW, chunks);
+        dim3 grid(gx, chunks);
         DW_DISPATCH(kk, d.stride, d.act, {
             hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT>), grid, dim3(256), shm, s, d, ddh, D, stats2, red2, E, stats1,
-                               gm);
+                               part, out_size, gm);
         })
+    }
+    size_t poff = 0;
+    for (int g = 0; g < d.G; ++g) {
+        const int n = d.g[g].mc * d.g[g].k * d.g[g].k;
+        int rc = launch_reduce_rows(part + poff, gx, n, out_size, nullptr, d.g[g].g_dw, s);
+        if (rc) return rc;
+        poff += n;
     }
     return (int)hipGetLastError();
 }

@@ -138,10 +138,13 @@ __device__ __forceinline__ void acc_colstats(const f32x4 (&acc)[2][NT], float (&
         }
 }
 
-// Block-reduce the per-lane column totals (over the 4 lane groups and 4 waves) and add them to the
-// double-precision (sum, sumsq) accumulators of columns [col0, col0+BN) that are < col_lim.
+// Block-reduce the per-lane column totals (over the 4 lane groups and 4 waves) and store them as this
+// workgroup's partial (sum, sumsq) pair for columns [col0, col0+BN) that are < col_lim.  `part_row` is the
+// workgroup's row of the partials matrix; a follow-up k_reduce_rows launch sums the rows in double precision.
+// (Device-scope atomics cost ~1 ns each on MI355X and a stats epilogue issued 10^5..10^6 of them per launch;
+//  partials + reduce is also bit-reproducible.)
 template <int NT>
-__device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], float* lds, double* stats,
+__device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], float* lds, float* part_row,
                                                int col0, int col_lim) {
     using T = GT<NT>;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15;
@@ -167,8 +170,8 @@ __device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], f
             ss += lds[(ww * 2 + 0) * T::BN + tid];
             qq += lds[(ww * 2 + 1) * T::BN + tid];
         }
-        atomic_add_f64(&stats[2 * (size_t)(col0 + tid) + 0], (double)ss);
-        atomic_add_f64(&stats[2 * (size_t)(col0 + tid) + 1], (double)qq);
+        part_row[2 * (size_t)(col0 + tid) + 0] = ss;
+        part_row[2 * (size_t)(col0 + tid) + 1] = qq;
     }
     __syncthreads();
 }

@@ -10,10 +10,10 @@
 
 // ============================================================================ expand forward
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
-// epilogue: per-channel (sum, sumsq) of E -> stats1 (BN1 batch statistics)
+// epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT>
 __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
-                                                    float* __restrict__ E, double* __restrict__ stats1) {
+                                                    float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     int ty = blockIdx.y, g = 0;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
             }
         acc_colstats<NT>(acc, cs, cq);
     }
-    flush_colstats<NT>(cs, cq, lds, stats1 + 2 * (size_t)off, n0, mc);
+    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp);
 }
 
 // ============================================================================ project forward
@@ -69,7 +69,7 @@ template <int NT, int ACT>
 __global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
-                                                     double* __restrict__ stats3) {
+                                                     float* __restrict__ part) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.z;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const floa
             }
         acc_colstats<NT>(acc, cs, cq);
     }
-    flush_colstats<NT>(cs, cq, lds, stats3 + 2 * (size_t)g * oc, n0, oc);
+    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
 }
 
 // ---------------------------------------------------------------------------- BN3-backward operand
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_project_dgrad(TfnasCellDesc d, const fl
 }
 
 // ============================================================================ project wgrad (TN, split-K)
-// g_proj_g[o][c] += sum_p dP_g[p][o] * z_g[p][c]       (atomics over the K-splits; buffer pre-zeroed)
+// part[split][poff_g + o*mc + c] = sum_{p in split} dP_g[p][o] * z_g[p][c]   (k_reduce_rows sums the splits)
 // tile: M side = mid channels c (128), N side = output channels o (16*NT)
 template <int NT, int ACT>
 __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const float* __restrict__ dout,
@@ -230,13 +230,15 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
                                                        const double* __restrict__ stats3,
                                                        const double* __restrict__ red3,
                                                        const float* __restrict__ wmix, int rows_per_split,
-                                                       int ntiles_o) {
+                                                       int ntiles_o, float* __restrict__ part, size_t out_size) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.z / ntiles_o, n0 = (blockIdx.z % ntiles_o) * T::BN;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0;
-    float* __restrict__ gw = d.g[g].g_proj;
+    size_t poff = 0;
+    for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * d.oc;
+    float* __restrict__ gw = part + (size_t)blockIdx.x * out_size + poff;
     const int m0 = blockIdx.y * 128;
     if (m0 >= mcp) return;
     const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int o = n0 + 16 * j + lr;
-                    if (o < oc) atomic_add_f32(gw + (size_t)o * mc + ch, acc[i][j][r]);
+                    if (o < oc) gw[(size_t)o * mc + ch] = acc[i][j][r];
                 }
             }
         }
@@ -371,11 +373,12 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
 }
 
 // ============================================================================ expand wgrad (TN, split-K)
-// g_expand_g[m][c] += sum_p de[p][off_g+m] * x[p][c]
+// part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]   (k_reduce_rows sums the splits)
 template <int NT>
 __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ E, const float* __restrict__ cb1,
-                                                      const float* __restrict__ x, int rows_per_split) {
+                                                      const float* __restrict__ x, int rows_per_split,
+                                                      float* __restrict__ part, size_t out_size) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     int ty = blockIdx.y, g = 0;
@@ -385,7 +388,9 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
         ty -= t;
     }
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
-    float* __restrict__ gw = d.g[g].g_expand;
+    size_t poff = 0;
+    for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * d.ic;
+    float* __restrict__ gw = part + (size_t)blockIdx.x * out_size + poff;
     const int m0 = ty * 128, n0 = blockIdx.z * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int r0 = blockIdx.x * rows_per_split, r1 = min(P, r0 + rows_per_split);
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int cc = n0 + 16 * j + lr;
-                    if (cc < ic) atomic_add_f32(gw + (size_t)ch * ic + cc, acc[i][j][r]);
+                    if (cc < ic) gw[(size_t)ch * ic + cc] = acc[i][j][r];
                 }
             }
         }
@@ -428,7 +433,6 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
 
 // ============================================================================ host launchers
 static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channel counts (ic / oc)
-static const int kNtWide[] = {4};                   // N extents that are mid-channel groups
 
 #define DISPATCH_NT(nt, ...)                                  \
     switch (nt) {                                             \
@@ -444,36 +448,41 @@ static const int kNtWide[] = {4};                   // N extents that are mid-ch
     if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; } \
     else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
 
-static int row_blocks(int rows, int other_blocks) {
+// number of persistent row-blocks: ~4096 workgroups in total, and (for kernels with a statistics epilogue)
+// at most `cap` so that the per-workgroup partials fit the scratch buffer
+static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30) {
     const int nrt = cdiv(rows, 128);
     int want = cdiv(4096, other_blocks > 0 ? other_blocks : 1);   // ~16 workgroups per CU in total
+    if ((size_t)want > cap) want = (int)cap;
     if (want < 1) want = 1;
     return nrt < want ? nrt : want;
 }
 
-int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, hipStream_t s) {
+int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
+                      hipStream_t s) {
     ProfScope _prof(TK_EXPAND_FWD, s);
     constexpr int NT = 4;
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles), tiles);
-    hipLaunchKernelGGL(k_expand_fwd<NT>, grid, dim3(256), 0, s, d, x, E, stats1);
-    return (int)hipGetLastError();
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, TFNAS_PART_FLOATS / (2 * (size_t)d.M)), tiles);
+    hipLaunchKernelGGL(k_expand_fwd<NT>, grid, dim3(256), 0, s, d, x, E, part);
+    return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
-                       float* Pr, double* stats3, hipStream_t s) {
+                       float* Pr, double* stats3, float* part, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_FWD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     int mcp_max = 0;
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int tiles = cdiv(d.oc, 16 * nt);
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G), tiles, d.G);
+    const int ncols2 = 2 * d.G * d.oc;
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, TFNAS_PART_FLOATS / (size_t)ncols2), tiles, d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, stats3);
+        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part);
     }))
-    return (int)hipGetLastError();
+    return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
 }
 
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
@@ -488,30 +497,42 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
     return (int)hipGetLastError();
 }
 
-static int pick_rows_per_split(int rows, int out_tiles) {
-    // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split
+static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
+    // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split, partial tiles must fit the scratch
     int splits = cdiv(1024, out_tiles > 0 ? out_tiles : 1);
-    int rps = cdiv(rows, splits > 0 ? splits : 1);
+    const size_t cap = TFNAS_PART_FLOATS / (out_size > 0 ? out_size : 1);
+    if ((size_t)splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    int rps = cdiv(rows, splits);
     if (rps < 256) rps = 256;
     return ((rps + 15) / 16) * 16;
 }
 
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
-                         const float* wmix, hipStream_t s) {
+                         const float* wmix, float* part, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_WGRAD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     const int Po = d.N * d.Ho * d.Wo;
     int mcp_max = 0;
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int mtiles = cdiv(mcp_max, 128), ntiles = cdiv(d.oc, 16 * nt);
-    const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G);
+    size_t out_size = 0;
+    for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.oc;
+    const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G, out_size);
     dim3 grid(cdiv(Po, rps), mtiles, ntiles * d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_wgrad<NT, ACT>), grid, dim3(256), shm, s, d, dout, Pr, D, gate, stats2,
-                           stats3, red3, wmix, rps, ntiles);
+                           stats3, red3, wmix, rps, ntiles, part, out_size);
     }))
+    size_t poff = 0;
+    for (int g = 0; g < d.G; ++g) {
+        const int n = d.g[g].mc * d.oc;
+        int rc = launch_reduce_rows(part + poff, grid.x, n, out_size, nullptr, d.g[g].g_proj, s);
+        if (rc) return rc;
+        poff += n;
+    }
     return (int)hipGetLastError();
 }
 
@@ -528,17 +549,26 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E
 }
 
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
-                        const float* x, hipStream_t s) {
+                        const float* x, float* part, hipStream_t s) {
     ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;
     int mtiles = 0;
     for (int g = 0; g < d.G; ++g) mtiles += cdiv(d.g[g].mcp, 128);
     const int ntiles = cdiv(d.ic, 16 * nt);
-    const int rps = pick_rows_per_split(P, mtiles * ntiles);
+    size_t out_size = 0;
+    for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.ic;
+    const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size);
     dim3 grid(cdiv(P, rps), mtiles, ntiles);
     DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_wgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps);
+        hipLaunchKernelGGL(k_expand_wgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
     })
+    size_t poff = 0;
+    for (int g = 0; g < d.G; ++g) {
+        const int n = d.g[g].mc * d.ic;
+        int rc = launch_reduce_rows(part + poff, grid.x, n, out_size, nullptr, d.g[g].g_expand, s);
+        if (rc) return rc;
+        poff += n;
+    }
     return (int)hipGetLastError();
 }

@@ -4,44 +4,50 @@
 #include "tfnas_hip.h"
 
 // gemm_kernels.hip
-int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, hipStream_t s);
+int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
+                      hipStream_t s);
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
-                       float* Pr, double* stats3, hipStream_t s);
+                       float* Pr, double* stats3, float* part, hipStream_t s);
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
                          const double* red3, const float* wmix, float* dZ, hipStream_t s);
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
-                         const float* wmix, hipStream_t s);
+                         const float* wmix, float* part, hipStream_t s);
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* dout, const float* wmix, float* dx, hipStream_t s);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
-                        const float* x, hipStream_t s);
+                        const float* x, float* part, hipStream_t s);
 
 // dwconv_kernels.hip
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
-                  hipStream_t s);
+                  float* part, hipStream_t s);
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
-                       hipStream_t s);
+                       float* part, hipStream_t s);
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
-                    const double* red2, const float* E, const double* stats1, hipStream_t s);
+                    const double* red2, const float* E, const double* stats1, float* part, hipStream_t s);
 
-// pointwise_kernels.hip (SE, BN2 backward statistics, mixing epilogue, BN constant tables)
+// pointwise_kernels.hip (SE squeeze, BN2 backward statistics, mixing epilogue, BN constant tables)
+// se_kernels.hip (SE excite FCs as small GEMMs: launch_se_fc_fwd / launch_se_fc_bwd / launch_se_wgrad)
 int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2, float* pooled, hipStream_t s);
 int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s);
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s);
 int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         const float* x, double* red3, double* resdot, hipStream_t s);
+                         const float* x, double* red3, float* part, hipStream_t s);
 int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resdot, float* dwmix, hipStream_t s);
 int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
                          float* dgate, hipStream_t s);
 int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
                      float* dgl, float* dhpre, float* dpooled, hipStream_t s);
-int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre, const float* hpre,
-                    const float* pooled, hipStream_t s);
+int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* dhpre,
+                    const float* hpre, const float* pooled, hipStream_t s);
 int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
-                   const float* dpooled, double* red2, hipStream_t s);
+                   const float* dpooled, double* red2, float* part, hipStream_t s);
+// out[c] = sum_{b<nb} part[b*stride + c]  (double and/or float output); the deterministic replacement of atomics
+int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
+                       hipStream_t s);
+#define TFNAS_PART_FLOATS ((size_t)4 << 20)   /* scratch for per-workgroup partials: 4 Mi floats = 16 MiB */
 int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,
                       hipStream_t s);
 

@@ -7,14 +7,18 @@
 #include "prof.h"
 
 // sum v over the threads of the block that share `col` (rows pr = 0..RP-1); result valid where pr == 0
+// (tree reduction over pr with all threads; a serial sum by the pr==0 threads cost ~16 us per workgroup)
 __device__ __forceinline__ f32x4 reduce_rows(f32x4 v, f32x4* buf, int pr, int col, int RP, int TQ, bool active) {
     __syncthreads();
     if (active) buf[pr * TQ + col] = v;
     __syncthreads();
-    f32x4 r = zero4();
-    if (active && pr == 0)
-        for (int q = 0; q < RP; ++q) r += buf[q * TQ + col];
-    return r;
+    int s = 1;
+    while (s * 2 < RP) s *= 2;
+    for (; s > 0; s >>= 1) {
+        if (active && pr < s && pr + s < RP) buf[pr * TQ + col] += buf[(pr + s) * TQ + col];
+        __syncthreads();
+    }
+    return (active && pr == 0) ? buf[col] : zero4();
 }
 
 // locate the `idx`-th chunk of CH channels among SE groups (se_only) or all groups
@@ -36,17 +40,6 @@ static int chunk_count(const TfnasCellDesc& d, int CH, bool se_only) {
         if (!se_only || d.g[g].se > 0) t += cdiv(d.g[g].mcp, CH);
     return t;
 }
-__device__ __forceinline__ int se_group(const TfnasCellDesc& d, int idx) {
-    for (int g = 0; g < d.G; ++g)
-        if (d.g[g].se > 0 && idx-- == 0) return g;
-    return -1;
-}
-static int se_group_count(const TfnasCellDesc& d) {
-    int t = 0;
-    for (int g = 0; g < d.G; ++g) t += d.g[g].se > 0;
-    return t;
-}
-
 // ============================================================================ SE squeeze (global average pool)
 // MODE 0: pooled[n][c] = mean_hw act(BN2(D))            (forward)
 // MODE 1: dgate [n][c] = sum_hw  dZ * act(BN2(D))       (backward of the gate multiply)
@@ -69,134 +62,29 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
                                         : make_float2(0.f, 0.f);
     f32x4 acc = zero4();
     if (active) {
-        for (int hw = rl; hw < HW; hw += 16) {
-            const size_t a = ((size_t)n * HW + hw) * M + off + ch;
-            f32x4 v = ld4(D + a);
+        for (int hw = rl; hw < HW; hw += 64) {        // 4 independent rows in flight per thread
+            f32x4 v[4], z[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
-            if (MODE == 1) v *= ld4(dZ + a);
-            acc += v;
+            for (int u = 0; u < 4; ++u) {
+                const int h = hw + 16 * u;
+                const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
+                v[u] = ld4(D + a);
+                z[u] = (MODE == 1) ? ld4(dZ + a) : zero4();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (hw + 16 * u < HW) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = act_f<ACT>((v[u][j] - c2[j].x) * c2[j].y);
+                    acc += (MODE == 1) ? v[u] * z[u] : v[u];
+                }
+            }
         }
     }
     acc = reduce_rows(acc, buf, rl, cq, 16, 16, active);
     if (active && rl == 0) {
         if (MODE == 0) acc *= splat4(1.f / (float)HW);
         st4(outp + (size_t)n * M + off + ch, acc);
-    }
-}
-
-// ============================================================================ SE excite (two 1x1 convs on [N, mc])
-// hpre = W_r pooled + b_r ; h = act(hpre) ; gate = sigmoid(W_e h + b_e)
-template <int ACT>
-__global__ __launch_bounds__(256) void k_se_fc_fwd(TfnasCellDesc d, const float* __restrict__ pooled,
-                                                   float* __restrict__ hpre, float* __restrict__ gate) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int g = se_group(d, blockIdx.y);
-    if (g < 0) return;
-    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
-    const float* __restrict__ wr = d.g[g].w_se_r;
-    const float* __restrict__ br = d.g[g].b_se_r;
-    const float* __restrict__ we = d.g[g].w_se_e;
-    const float* __restrict__ be = d.g[g].b_se_e;
-    const int n = blockIdx.x, M = d.M, SE = d.SE;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float* pl = lds;
-    float* hs = lds + mcp;
-    for (int c = tid; c < mc; c += 256) pl[c] = pooled[(size_t)n * M + off + c];
-    __syncthreads();
-    for (int j = wv; j < se; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < mc; c += 64) s += wr[(size_t)j * mc + c] * pl[c];
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float hp = s + br[j];
-            hpre[(size_t)n * SE + so + j] = hp;
-            hs[j] = act_f<ACT>(hp);
-        }
-    }
-    __syncthreads();
-    for (int c = wv; c < mcp; c += 4) {
-        float s = 0.f;
-        if (c < mc)
-            for (int j = lane; j < se; j += 64) s += we[(size_t)c * se + j] * hs[j];
-        s = wave_sum(s);
-        if (lane == 0) gate[(size_t)n * M + off + c] = (c < mc) ? sigmoid_f(s + be[c]) : 0.f;
-    }
-}
-
-// backward of the excite FCs for one sample:
-//   dgl = dgate * g (1-g) ; dh = W_e^T dgl ; dhpre = dh * act'(hpre) ; dpooled = W_r^T dhpre
-template <int ACT>
-__global__ __launch_bounds__(256) void k_se_fc_bwd(TfnasCellDesc d, const float* __restrict__ dgate,
-                                                   const float* __restrict__ gate, const float* __restrict__ hpre,
-                                                   float* __restrict__ dgl, float* __restrict__ dhpre,
-                                                   float* __restrict__ dpooled) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int g = se_group(d, blockIdx.y);
-    if (g < 0) return;
-    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
-    const float* __restrict__ wr = d.g[g].w_se_r;
-    const float* __restrict__ we = d.g[g].w_se_e;
-    const int n = blockIdx.x, M = d.M, SE = d.SE, tid = threadIdx.x;
-    float* dgs = lds;
-    float* dhs = lds + mcp;
-    for (int c = tid; c < mcp; c += 256) {
-        float v = 0.f;
-        if (c < mc) {
-            const float gt = gate[(size_t)n * M + off + c];
-            v = dgate[(size_t)n * M + off + c] * gt * (1.f - gt);
-        }
-        dgs[c] = v;
-        dgl[(size_t)n * M + off + c] = v;
-    }
-    __syncthreads();
-    for (int j = tid; j < se; j += 256) {
-        float s = 0.f;
-        for (int c = 0; c < mc; ++c) s += we[(size_t)c * se + j] * dgs[c];
-        const float v = s * act_d<ACT>(hpre[(size_t)n * SE + so + j]);
-        dhs[j] = v;
-        dhpre[(size_t)n * SE + so + j] = v;
-    }
-    __syncthreads();
-    for (int c = tid; c < mcp; c += 256) {
-        float s = 0.f;
-        if (c < mc)
-            for (int j = 0; j < se; ++j) s += wr[(size_t)j * mc + c] * dhs[j];
-        dpooled[(size_t)n * M + off + c] = s;
-    }
-}
-
-// weight gradients of the excite FCs (sums over the batch), one element per thread
-template <int ACT>
-__global__ __launch_bounds__(256) void k_se_wgrad(TfnasCellDesc d, const float* __restrict__ dgl,
-                                                  const float* __restrict__ dhpre, const float* __restrict__ hpre,
-                                                  const float* __restrict__ pooled) {
-    const int g = se_group(d, blockIdx.y);
-    if (g < 0) return;
-    const int mc = d.g[g].mc, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
-    const int N = d.N, M = d.M, SE = d.SE;
-    const long total = 2L * mc * se + mc + se;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        float s = 0.f;
-        if (idx < (long)mc * se) {                       // g_se_e[c][j] = sum_n dgl[n][c] * h[n][j]
-            const int c = (int)(idx / se), j = (int)(idx % se);
-            for (int n = 0; n < N; ++n)
-                s += dgl[(size_t)n * M + off + c] * act_f<ACT>(hpre[(size_t)n * SE + so + j]);
-            d.g[g].g_se_e[idx] = s;
-        } else if (idx < 2L * mc * se) {                 // g_se_r[j][c] = sum_n dhpre[n][j] * pooled[n][c]
-            const long i2 = idx - (long)mc * se;
-            const int j = (int)(i2 / mc), c = (int)(i2 % mc);
-            for (int n = 0; n < N; ++n) s += dhpre[(size_t)n * SE + so + j] * pooled[(size_t)n * M + off + c];
-            d.g[g].g_se_r[i2] = s;
-        } else if (idx < 2L * mc * se + mc) {            // gb_se_e[c]
-            const int c = (int)(idx - 2L * mc * se);
-            for (int n = 0; n < N; ++n) s += dgl[(size_t)n * M + off + c];
-            d.g[g].gb_se_e[c] = s;
-        } else {                                         // gb_se_r[j]
-            const int j = (int)(idx - 2L * mc * se - mc);
-            for (int n = 0; n < N; ++n) s += dhpre[(size_t)n * SE + so + j];
-            d.g[g].gb_se_r[j] = s;
-        }
     }
 }
 
@@ -239,8 +127,8 @@ __global__ __launch_bounds__(256) void k_mix_fwd(TfnasCellDesc d, const float* _
 __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
-                                                       const float* __restrict__ x, double* __restrict__ red3,
-                                                       double* __restrict__ resdot, int rows_per_block) {
+                                                       const float* __restrict__ x, float* __restrict__ part,
+                                                       int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int oc = d.oc, G = d.G, TQ = oc >> 2, RP = 256 / TQ;
     const int Po = d.N * d.Ho * d.Wo;
@@ -272,11 +160,11 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
             }
         }
     }
+    // this workgroup's row of the partials matrix: [G*oc][2] (S1,S2) followed by [oc] partial <dout,x> sums
+    float* prow = part + (size_t)blockIdx.x * (2 * G * oc + oc);
     s1 = reduce_rows(s1, buf, pr, oq, RP, TQ, active);
-    if (d.has_res) {
-        sx = reduce_rows(sx, buf, pr, oq, RP, TQ, active);
-        if (active && pr == 0) atomic_add_f64(resdot, (double)((sx.x + sx.y) + (sx.z + sx.w)));
-    }
+    sx = reduce_rows(sx, buf, pr, oq, RP, TQ, active);
+    if (active && pr == 0) st4(prow + 2 * G * oc + o, sx);
 #pragma unroll
     for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
         if (g < G) {
@@ -284,8 +172,8 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
             if (active && pr == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    atomic_add_f64(red3 + 2 * ((size_t)g * oc + o + j) + 0, (double)s1[j]);
-                    atomic_add_f64(red3 + 2 * ((size_t)g * oc + o + j) + 1, (double)r[j]);
+                    prow[2 * ((size_t)g * oc + o + j) + 0] = s1[j];
+                    prow[2 * ((size_t)g * oc + o + j) + 1] = r[j];
                 }
             }
         }
@@ -293,11 +181,14 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
 }
 
 // dwmix[g] = d loss / d wmix[g] = <dout, phat_g [+ x]> = sum_o S2[g][o] [+ <dout,x>]
+// resdot[o] = per-channel <dout,x> sums (residual cells), stored right after red3
 __global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const double* __restrict__ resdot,
                          float* __restrict__ dwmix) {
     const int g = threadIdx.x;
     if (g < d.G) {
-        double s = d.has_res ? resdot[0] : 0.0;
+        double s = 0.0;
+        if (d.has_res)
+            for (int o = 0; o < d.oc; ++o) s += resdot[o];
         for (int o = 0; o < d.oc; ++o) s += red3[2 * ((size_t)g * d.oc + o) + 1];
         dwmix[g] = (float)s;
     }
@@ -308,7 +199,7 @@ __global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const
 template <int ACT>
 __global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, float* __restrict__ dZ, const float* __restrict__ D,
                                                  const double* __restrict__ stats2, const float* __restrict__ gate,
-                                                 const float* __restrict__ dpooled, double* __restrict__ red2,
+                                                 const float* __restrict__ dpooled, float* __restrict__ part,
                                                  int rows_per_block) {
     __shared__ f32x4 buf[256];
     int g, c0;
@@ -328,34 +219,47 @@ __global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, float* __restr
     const int p0 = blockIdx.x * rows_per_block, p1 = min(Po, p0 + rows_per_block);
     f32x4 r1 = zero4(), r2 = zero4();
     if (active) {
-        for (int p = p0 + rl; p < p1; p += 16) {
-            const size_t a = (size_t)p * M + off + ch;
-            f32x4 da = ld4(dZ + a);
-            const f32x4 dv = ld4(D + a);
-            if (has_se) {
-                const size_t b = (size_t)(p / HW) * M + off + ch;
-                da = da * ld4(gate + b) + ld4(dpooled + b) * splat4(inv_hw);
-            }
-            f32x4 ddh;
+        for (int pb = p0 + rl; pb < p1; pb += 64) {          // 4 independent rows in flight per thread
+            f32x4 da[4], dv[4], gt[4], dp[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dh = (dv[j] - c2[j].x) * c2[j].y;
-                ddh[j] = da[j] * act_d<ACT>(dh);
-                r1[j] += ddh[j];
-                r2[j] += ddh[j] * dh;
+            for (int u = 0; u < 4; ++u) {
+                const int p = pb + 16 * u < p1 ? pb + 16 * u : pb;
+                const size_t a = (size_t)p * M + off + ch;
+                da[u] = ld4(dZ + a);
+                dv[u] = ld4(D + a);
+                if (has_se) {
+                    const size_t b = (size_t)(p / HW) * M + off + ch;
+                    gt[u] = ld4(gate + b);
+                    dp[u] = ld4(dpooled + b);
+                }
             }
-            st4(dZ + a, ddh);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pb + 16 * u;
+                if (p < p1) {
+                    if (has_se) da[u] = da[u] * gt[u] + dp[u] * splat4(inv_hw);
+                    f32x4 ddh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dh = (dv[u][j] - c2[j].x) * c2[j].y;
+                        ddh[j] = da[u][j] * act_d<ACT>(dh);
+                        r1[j] += ddh[j];
+                        r2[j] += ddh[j] * dh;
+                    }
+                    st4(dZ + (size_t)p * M + off + ch, ddh);
+                }
+            }
         }
     }
     r1 = reduce_rows(r1, buf, rl, cq, 16, 16, active);
     r2 = reduce_rows(r2, buf, rl, cq, 16, 16, active);
     if (active && rl == 0) {
+        float* prow = part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)(off + ch);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ch + j < mc) {
-                atomic_add_f64(red2 + 2 * (size_t)(off + ch + j) + 0, (double)r1[j]);
-                atomic_add_f64(red2 + 2 * (size_t)(off + ch + j) + 1, (double)r2[j]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            prow[2 * j + 0] = r1[j];
+            prow[2 * j + 1] = r2[j];
+        }
     }
 }
 
@@ -377,6 +281,39 @@ __global__ void k_bn1_consts(TfnasCellDesc d, const double* __restrict__ stats1,
         if (c >= d.g[g].off && c < d.g[g].off + d.g[g].mc) is_pad = false;
     if (is_pad) t = zero4();
     reinterpret_cast<f32x4*>(cb1)[c] = t;
+}
+
+// ============================================================================ partials -> totals
+// out[c] = sum_{b < nb} part[b*stride + c]   (summed in double; 16 columns x 16 row-lanes per workgroup)
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int nb, int ncols, size_t stride,
+                                                     double* __restrict__ out_d, float* __restrict__ out_f) {
+    __shared__ double buf[16][17];
+    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0;
+    if (c < ncols) {
+        for (int b = rl; b < nb; b += 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (b + 16 * u < nb) ? part[(size_t)(b + 16 * u) * stride + c] : 0.f;
+            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+        }
+    }
+    buf[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < ncols) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += buf[r][cl];
+        if (out_d) out_d[c] = t;
+        if (out_f) out_f[c] = (float)t;
+    }
+}
+
+int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(ncols, 16)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+    return (int)hipGetLastError();
 }
 
 // ============================================================================ host launchers
@@ -407,57 +344,6 @@ int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D
     return (int)hipGetLastError();
 }
 
-static size_t se_fc_shm(const TfnasCellDesc& d) {
-    int m = 0;
-    for (int g = 0; g < d.G; ++g)
-        if (d.g[g].se > 0 && d.g[g].mcp + d.g[g].se > m) m = d.g[g].mcp + d.g[g].se;
-    return (size_t)(m + 4) * sizeof(float);
-}
-
-int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s) {
-    ProfScope _prof(TK_SE_FC_FWD, s);
-    const int ng = se_group_count(d);
-    if (!ng) return 0;
-    dim3 grid(d.N, ng);
-    ACT_DISPATCH(d.act, {
-        hipLaunchKernelGGL((k_se_fc_fwd<ACT>), grid, dim3(256), se_fc_shm(d), s, d, pooled, hpre, gate);
-    })
-    return (int)hipGetLastError();
-}
-
-int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
-                     float* dgl, float* dhpre, float* dpooled, hipStream_t s) {
-    ProfScope _prof(TK_SE_FC_BWD, s);
-    const int ng = se_group_count(d);
-    if (!ng) return 0;
-    dim3 grid(d.N, ng);
-    ACT_DISPATCH(d.act, {
-        hipLaunchKernelGGL((k_se_fc_bwd<ACT>), grid, dim3(256), se_fc_shm(d), s, d, dgate, gate, hpre, dgl, dhpre,
-                           dpooled);
-    })
-    return (int)hipGetLastError();
-}
-
-int launch_se_wgrad(const TfnasCellDesc& d, const float* dgl, const float* dhpre, const float* hpre,
-                    const float* pooled, hipStream_t s) {
-    ProfScope _prof(TK_SE_WGRAD, s);
-    const int ng = se_group_count(d);
-    if (!ng) return 0;
-    long mx = 0;
-    for (int g = 0; g < d.G; ++g)
-        if (d.g[g].se > 0) {
-            const long t = 2L * d.g[g].mc * d.g[g].se + d.g[g].mc + d.g[g].se;
-            mx = t > mx ? t : mx;
-        }
-    int bx = (int)((mx + 255) / 256);
-    if (bx > 2048) bx = 2048;
-    dim3 grid(bx, ng);
-    ACT_DISPATCH(d.act, {
-        hipLaunchKernelGGL((k_se_wgrad<ACT>), grid, dim3(256), 0, s, d, dgl, dhpre, hpre, pooled);
-    })
-    return (int)hipGetLastError();
-}
-
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s) {
     ProfScope _prof(TK_MIX_FWD, s);
@@ -471,16 +357,19 @@ int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3
 }
 
 int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         const float* x, double* red3, double* resdot, hipStream_t s) {
+                         const float* x, double* red3, float* part, hipStream_t s) {
     ProfScope _prof(TK_MIX_BWD_STATS, s);
     const int Po = d.N * d.Ho * d.Wo;
-    int rpb = cdiv(Po, 1024);
+    const int ncols = 2 * d.G * d.oc + d.oc;       // (S1,S2) pairs + per-channel <dout,x>; reduced into red3|resdot
+    size_t nblk = 1024;
+    if (nblk > TFNAS_PART_FLOATS / (size_t)ncols) nblk = TFNAS_PART_FLOATS / (size_t)ncols;
+    int rpb = cdiv(Po, (int)nblk);
     const int RP = 256 / (d.oc / 4);
     if (rpb < 8 * RP) rpb = 8 * RP;
     const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
-    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(cdiv(Po, rpb)), dim3(256), shm, s, d, dout, Pr, stats3, x, red3, resdot,
-                       rpb);
-    return (int)hipGetLastError();
+    const int gx = cdiv(Po, rpb);
+    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
+    return launch_reduce_rows(part, gx, ncols, (size_t)ncols, red3, nullptr, s);
 }
 
 int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resdot, float* dwmix, hipStream_t s) {
@@ -490,18 +379,20 @@ int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resd
 }
 
 int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
-                   const float* dpooled, double* red2, hipStream_t s) {
+                   const float* dpooled, double* red2, float* part, hipStream_t s) {
     ProfScope _prof(TK_BN2_BWD, s);
     const int Po = d.N * d.Ho * d.Wo;
     const int chunks = chunk_count(d, 64, false);
-    int want = cdiv(2048, chunks);
+    int want = cdiv(4096, chunks);
+    const size_t cap = TFNAS_PART_FLOATS / (2 * (size_t)d.M);
+    if ((size_t)want > cap) want = (int)cap;
     int rpb = cdiv(Po, want < 1 ? 1 : want);
     if (rpb < 64) rpb = 64;
     dim3 grid(cdiv(Po, rpb), chunks);
     ACT_DISPATCH(d.act, {
-        hipLaunchKernelGGL((k_bn2_bwd<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, gate, dpooled, red2, rpb);
+        hipLaunchKernelGGL((k_bn2_bwd<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, gate, dpooled, part, rpb);
     })
-    return (int)hipGetLastError();
+    return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, red2, nullptr, s);
 }
 
 int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,

@@ -1,0 +1,223 @@
+// Squeeze-excite "excite" stage (two 1x1 convs on the pooled [N, mc] tensor) as small fp32 MFMA GEMMs with the
+// batch dimension as GEMM rows, forward / backward / weight gradients.
+//
+// Reference: squeeze_excite = conv_reduce(+bias) -> act -> conv_expand(+bias), gate = sigmoid(.)
+//            (models/layers.py:509-526, forward :548-550) and its autograd backward.
+//
+//   MODE 0  hpre [N,se] = pooled[N,mc] W_r^T + b_r                                   (NT)
+//   MODE 1  gate [N,mc] = sigmoid(act(hpre)[N,se] W_e^T + b_e)                       (NT)
+//   MODE 2  dhpre[N,se] = (dgl[N,mc] W_e) * act'(hpre),  dgl = dgate*gate*(1-gate)   (NN)
+//   MODE 3  dpool[N,mc] = dhpre[N,se] W_r                                            (NN)
+//   MODE 4  g_se_e[mc,se] = dgl^T act(hpre)                                          (TN, K = batch)
+//   MODE 5  g_se_r[se,mc] = (pooled^T dhpre)^T                                       (TN, K = batch)
+#include "gemm_core.h"
+#include "kernels.h"
+#include "prof.h"
+
+struct SeArgs {
+    const float* pooled;   // [N][M]
+    const float* gate;     // [N][M]
+    const float* hpre;     // [N][SE]
+    const float* dgate;    // [N][M]
+    const float* dhpre;    // [N][SE]
+    float* out0;           // mode-dependent output
+};
+
+__device__ __forceinline__ int se_group_idx(const TfnasCellDesc& d, int idx) {
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0 && idx-- == 0) return g;
+    return -1;
+}
+
+template <int MODE, int ACT>
+__global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
+    constexpr int NT = 4;
+    using T = GT<NT>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    const int g = se_group_idx(d, blockIdx.z);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int N = d.N, M = d.M, SE = d.SE;
+    const bool mc_al = (mc & 3) == 0;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    const int r0 = blockIdx.x * 128;         // first GEMM row of this tile
+    const int n0 = blockIdx.y * T::BN;       // first GEMM column
+    f32x4 acc[2][NT];
+    acc_zero<NT>(acc);
+
+    auto dgl4 = [&](int n, int ch) -> f32x4 {       // d loss / d (pre-sigmoid gate), 4 channels
+        const f32x4 gt = ld4(a.gate + (size_t)n * M + off + ch);
+        const f32x4 dg = ld4(a.dgate + (size_t)n * M + off + ch);
+        return dg * gt * (splat4(1.f) - gt);
+    };
+    auto h4 = [&](int n, int j) -> f32x4 { return act_f4<ACT>(ld4(a.hpre + (size_t)n * SE + so + j)); };
+
+    if (MODE == 0) {
+        if (r0 >= N || n0 >= se) return;
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int n = r0 + row, k = c * 16 + kl;
+            return (n < N && k < mcp) ? ld4(a.pooled + (size_t)n * M + off + k) : zero4();
+        };
+        auto fb = [&](int c, int nn, int kl) -> f32x4 {
+            const int j = n0 + nn, k = c * 16 + kl;
+            return (j < se) ? ld4_guard(d.g[g].w_se_r + (size_t)j * mc, k, mc, mc_al) : zero4();
+        };
+        gemm_mainloop<NT, true, true>(fa, fb, (mcp + 15) >> 4, acc, lds);
+    } else if (MODE == 1) {
+        if (r0 >= N || n0 >= mcp) return;
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int n = r0 + row, k = c * 16 + kl;
+            return (n < N && k < se) ? h4(n, k) : zero4();
+        };
+        auto fb = [&](int c, int nn, int kl) -> f32x4 {
+            const int col = n0 + nn, k = c * 16 + kl;
+            return (col < mc && k < se) ? ld4(d.g[g].w_se_e + (size_t)col * se + k) : zero4();
+        };
+        gemm_mainloop<NT, true, true>(fa, fb, (se + 15) >> 4, acc, lds);
+    } else if (MODE == 2) {
+        if (r0 >= N || n0 >= se) return;
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int n = r0 + row, k = c * 16 + kl;
+            return (n < N && k < mcp) ? dgl4(n, k) : zero4();
+        };
+        auto fb = [&](int c, int kl, int nn) -> f32x4 {
+            const int k = c * 16 + kl, j = n0 + nn;
+            return (k < mc && j < se) ? ld4(d.g[g].w_se_e + (size_t)k * se + j) : zero4();
+        };
+        gemm_mainloop<NT, true, false>(fa, fb, (mcp + 15) >> 4, acc, lds);
+    } else if (MODE == 3) {
+        if (r0 >= N || n0 >= mcp) return;
+        auto fa = [&](int c, int row, int kl) -> f32x4 {
+            const int n = r0 + row, k = c * 16 + kl;
+            return (n < N && k < se) ? ld4(a.dhpre + (size_t)n * SE + so + k) : zero4();
+        };
+        auto fb = [&](int c, int kl, int nn) -> f32x4 {
+            const int k = c * 16 + kl;
+            return (k < se) ? ld4_guard(d.g[g].w_se_r + (size_t)k * mc, n0 + nn, mc, mc_al) : zero4();
+        };
+        gemm_mainloop<NT, true, false>(fa, fb, (se + 15) >> 4, acc, lds);
+    } else {   // MODE 4 / 5: rows = mid channels, cols = se, K = batch
+        if (r0 >= mcp || n0 >= se) return;
+        auto fa = [&](int c, int kl, int m) -> f32x4 {
+            const int n = c * 16 + kl, ch = r0 + m;
+            if (n >= N || ch >= mcp) return zero4();
+            return MODE == 4 ? dgl4(n, ch) : ld4(a.pooled + (size_t)n * M + off + ch);
+        };
+        auto fb = [&](int c, int kl, int nn) -> f32x4 {
+            const int n = c * 16 + kl, j = n0 + nn;
+            if (n >= N || j >= se) return zero4();
+            return MODE == 4 ? h4(n, j) : ld4(a.dhpre + (size_t)n * SE + so + j);
+        };
+        gemm_mainloop<NT, false, false>(fa, fb, (N + 15) >> 4, acc, lds);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + wrow + 16 * i + 4 * lq + r;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + 16 * j + lr;
+                const float v = acc[i][j][r];
+                if (MODE == 0) {
+                    if (row < N && col < se) a.out0[(size_t)row * SE + so + col] = v + d.g[g].b_se_r[col];
+                } else if (MODE == 1) {
+                    if (row < N && col < mcp)
+                        a.out0[(size_t)row * M + off + col] = col < mc ? sigmoid_f(v + d.g[g].b_se_e[col]) : 0.f;
+                } else if (MODE == 2) {
+                    if (row < N && col < se)
+                        a.out0[(size_t)row * SE + so + col] = v * act_d<ACT>(a.hpre[(size_t)row * SE + so + col]);
+                } else if (MODE == 3) {
+                    if (row < N && col < mcp) a.out0[(size_t)row * M + off + col] = v;
+                } else if (MODE == 4) {
+                    if (row < mc && col < se) d.g[g].g_se_e[(size_t)row * se + col] = v;
+                } else {
+                    if (row < mc && col < se) d.g[g].g_se_r[(size_t)col * mc + row] = v;
+                }
+            }
+        }
+}
+
+// bias gradients: gb_se_e[c] = sum_n dgl[n][c] ; gb_se_r[j] = sum_n dhpre[n][j]
+__global__ __launch_bounds__(256) void k_se_bias_grad(TfnasCellDesc d, SeArgs a) {
+    const int g = se_group_idx(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int N = d.N, M = d.M, SE = d.SE;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < mc) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float gt = a.gate[(size_t)n * M + off + idx];
+            s += a.dgate[(size_t)n * M + off + idx] * gt * (1.f - gt);
+        }
+        d.g[g].gb_se_e[idx] = s;
+    } else if (idx < mc + se) {
+        const int j = idx - mc;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += a.dhpre[(size_t)n * SE + so + j];
+        d.g[g].gb_se_r[j] = s;
+    }
+}
+
+// ============================================================================ host launchers
+static int se_count(const TfnasCellDesc& d, int& mcp_max, int& se_max) {
+    int t = 0;
+    mcp_max = se_max = 0;
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0) {
+            ++t;
+            if (d.g[g].mcp > mcp_max) mcp_max = d.g[g].mcp;
+            if (d.g[g].se > se_max) se_max = d.g[g].se;
+        }
+    return t;
+}
+
+#define SE_LAUNCH(MODE_, rows, cols)                                                                     \
+    {                                                                                                    \
+        dim3 grid(cdiv((rows), 128), cdiv((cols), 64), ng);                                              \
+        if (d.act == TFNAS_ACT_RELU)                                                                     \
+            hipLaunchKernelGGL((k_se_gemm<MODE_, TFNAS_ACT_RELU>), grid, dim3(256), 0, s, d, a);         \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_se_gemm<MODE_, TFNAS_ACT_SWISH>), grid, dim3(256), 0, s, d, a);        \
+    }
+
+int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s) {
+    ProfScope _prof(TK_SE_FC_FWD, s);
+    int mcp_max, se_max;
+    const int ng = se_count(d, mcp_max, se_max);
+    if (!ng) return 0;
+    SeArgs a = {pooled, gate, hpre, nullptr, nullptr, hpre};
+    SE_LAUNCH(0, d.N, se_max)
+    a.out0 = gate;
+    SE_LAUNCH(1, d.N, mcp_max)
+    return (int)hipGetLastError();
+}
+
+int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
+                     float* dgl, float* dhpre, float* dpooled, hipStream_t s) {
+    ProfScope _prof(TK_SE_FC_BWD, s);
+    (void)dgl;
+    int mcp_max, se_max;
+    const int ng = se_count(d, mcp_max, se_max);
+    if (!ng) return 0;
+    SeArgs a = {nullptr, gate, hpre, dgate, dhpre, dhpre};
+    SE_LAUNCH(2, d.N, se_max)
+    a.out0 = dpooled;
+    SE_LAUNCH(3, d.N, mcp_max)
+    return (int)hipGetLastError();
+}
+
+int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* dhpre,
+                    const float* hpre, const float* pooled, hipStream_t s) {
+    ProfScope _prof(TK_SE_WGRAD, s);
+    int mcp_max, se_max;
+    const int ng = se_count(d, mcp_max, se_max);
+    if (!ng) return 0;
+    SeArgs a = {pooled, gate, hpre, dgate, dhpre, nullptr};
+    SE_LAUNCH(4, mcp_max, se_max)
+    SE_LAUNCH(5, mcp_max, se_max)
+    hipLaunchKernelGGL(k_se_bias_grad, dim3(cdiv(mcp_max + se_max, 256), ng), dim3(256), 0, s, d, a);
+    return (int)hipGetLastError();
+}

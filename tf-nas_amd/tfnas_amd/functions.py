@@ -103,14 +103,14 @@ class MixedOpFn(torch.autograd.Function):
         Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
         fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
         stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
         if wmix is not None:
             wmix = wmix.contiguous()
         check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                           ptr(stats), ptr(out), _stream()), 'tfnas_mixedop_fwd')
+                                           ptr(stats), ptr(part), ptr(out), _stream()), 'tfnas_mixedop_fwd')
         ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
         ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
-        ctx.debug = None
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -128,11 +128,12 @@ class MixedOpFn(torch.autograd.Function):
         dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
         bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
         red = torch.empty(ws.red, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
         dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
         check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                            ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
-                                           ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+                                           ptr(part), ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
         d.need_wgrad = 0
         if MixedOpFn.debug_sink is not None:
             MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
