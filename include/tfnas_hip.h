@@ -36,6 +36,14 @@ extern "C" {
 #define TFNAS_MAX_SINK 4
 #define TFNAS_MAX_CELLS 32
 
+/* TfnasCellDesc.mode */
+#define TFNAS_MODE_CELL 0   /* a MixedOP cell: 1x1 expand from an NHWC input (default)                          */
+#define TFNAS_MODE_STEM 1   /* first_stem + second_stem (model_search.py:219-220) as ONE cell whose "expand" is the
+                               3x3 stride-2 pad-1 convolution of the 3-channel NCHW image (x = image, ic = 27 =
+                               im2col depth, w_expand = first_stem.conv.weight [32][3*3*3]); G = 1, no dx           */
+#define TFNAS_MODE_HEAD 2   /* feature_mix_layer + global average pool (model_search.py:299-300): E = x W^T,
+                               pooled = mean_hw act(BN(E)); only tfnas_head_fwd/bwd accept it                      */
+
 #define TFNAS_ACT_RELU 0
 #define TFNAS_ACT_SWISH 1
 
@@ -75,7 +83,9 @@ typedef struct TfnasCellDesc {
     int32_t M;                /* sum of mcp over groups                             [plan] */
     int32_t SE;               /* sum of se over groups                              [plan] */
     float eps;                /* BatchNorm eps (1e-5)                               [in] */
-    int32_t pad0;
+    int32_t mode;             /* TFNAS_MODE_CELL / _STEM / _HEAD                    [in] */
+    int32_t Hi, Wi;           /* stem mode: height / width of the NCHW input image  [in] */
+    int32_t pad0, pad1, pad2;
     TfnasGroup g[TFNAS_MAX_GROUPS];
 } TfnasCellDesc;
 
@@ -132,6 +142,16 @@ int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
                       const double *stats, const float *dout,
                       float *dZ, float *dEh, float *bsmall, double *red, float *part,
                       float *dx, float *dwmix, void *stream);
+
+/* Network head (mode TFNAS_MODE_HEAD): pooled[N][mc] = mean over pixels of act(BN(x W_expand^T)).
+ * Replaces feature_mix_layer (ConvLayer 1x1 + BN + swish) + AdaptiveAvgPool2d(1), models/model_search.py:299-300.
+ * Buffers: E [N*H*W][M], stats doubles [M][2], part = scratch (ws.part floats). */
+int tfnas_head_fwd(const TfnasCellDesc *d, const float *x, float *E, double *stats, float *part, float *pooled,
+                   void *stream);
+/* Backward of tfnas_head_fwd: dx [N*H*W][ic] and (need_wgrad) g_expand.  dEh [N*H*W][M], cb1 [M][4] floats and
+ * red doubles [M][2] are scratch. */
+int tfnas_head_bwd(const TfnasCellDesc *d, const float *x, const float *E, const double *stats, const float *dpooled,
+                   float *dEh, float *cb1, double *red, float *part, float *dx, void *stream);
 
 /* Gumbel-softmax over the candidates of `ncell` cells in one launch + expected cell latency.
  *   w[c][i] = softmax_i((log_alpha[c][i] - log(e[c][i])) / T)      (F.gumbel_softmax, model_search.py:87)

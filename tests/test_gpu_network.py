@@ -131,3 +131,42 @@ def test_search_steps_teacher_forced_and_free_running(lut):
     # architecture-level agreement at the end of the free run
     for a, b in zip(o.arch_parameters(), m.arch_parameters()):
         assert int(a.argmax()) == int(b.argmax()) or float((b.cpu() - a).abs().max()) < 5e-3
+
+
+def test_whole_net_weight_gradients_incl_stem_and_head(lut):
+    """One sampled (gumbel) forward/backward: every weight gradient -- including first_stem / second_stem (stem cell,
+    im2col expand) and feature_mix_layer / classifier (head) -- against the oracle."""
+    o, m = _pair(lut)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (4,), generator=g)
+    noise = torch.empty(18, 8).exponential_(generator=g)
+    lo, _ = o(x, True, 'gumbel', exp_noise=noise)
+    lm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    assert [c.last_idx for c in o.cells()] == [c.last_idx for c in m.cells()]
+    assert torch.allclose(lm.cpu(), lo, atol=1e-3, rtol=1e-3)
+    torch.nn.functional.cross_entropy(lo, y).backward()
+    torch.nn.functional.cross_entropy(lm, y.cuda()).backward()
+    checked = 0
+    for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
+        if a.grad is None:
+            assert b.grad is None, k
+            continue
+        assert b.grad is not None, k
+        err, ref = float((b.grad.cpu() - a.grad).abs().max()), float(a.grad.abs().max())
+        assert err <= 2e-5 + 2e-3 * ref, (k, err, ref)
+        checked += 1
+    assert checked > 60
+    o.reset_switches(); m.reset_switches()
+
+
+def test_stem_rejects_non_rgb_and_handles_odd_image_sizes(lut):
+    _, m = _pair(lut)
+    with pytest.raises(RuntimeError):
+        m._stem(torch.zeros(1, 4, 32, 32).cuda())
+    o, _ = _pair(lut)
+    x = torch.randn(2, 3, 37, 45)
+    import torch.nn.functional as F
+    ref = o.second_stem(F.relu(orc._bn(F.conv2d(x, o.first_stem.conv.weight, None, 2, 1))))
+    got = m._stem(x.cuda())
+    assert got.shape == ref.shape and torch.allclose(got.cpu(), ref, atol=1e-4, rtol=1e-3)

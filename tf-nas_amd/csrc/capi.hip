@@ -15,8 +15,17 @@ extern "C" uint64_t tfnas_sizeof(int which) {
 extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (!d) return TFNAS_ENULL;
     if (d->G < 1 || d->G > TFNAS_MAX_GROUPS) return TFNAS_ERANGE;
-    if (d->N < 1 || d->H < 1 || d->W < 1 || d->ic < 4 || d->oc < 4) return TFNAS_EINVAL;
-    if ((d->ic & 3) || (d->oc & 3)) return TFNAS_EINVAL;
+    if (d->mode < TFNAS_MODE_CELL || d->mode > TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (d->mode == TFNAS_MODE_STEM) {
+        /* x is the NCHW image; the 3x3 stride-2 pad-1 stem conv defines the cell's input extent */
+        if (d->ic != 27 || d->G != 1 || d->Hi < 1 || d->Wi < 1 || d->has_res) return TFNAS_EINVAL;
+        d->H = (d->Hi - 1) / 2 + 1;
+        d->W = (d->Wi - 1) / 2 + 1;
+    } else if (d->ic < 4 || (d->ic & 3)) {
+        return TFNAS_EINVAL;
+    }
+    if (d->mode == TFNAS_MODE_HEAD && d->G != 1) return TFNAS_EINVAL;
+    if (d->N < 1 || d->H < 1 || d->W < 1 || d->oc < 4 || (d->oc & 3)) return TFNAS_EINVAL;
     if (d->oc > 1024) return TFNAS_EINVAL;
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
     if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
@@ -85,6 +94,7 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
                                  float* Pr, float* fsmall, double* stats, float* part, float* out, void* stream) {
     if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
+    if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
@@ -107,9 +117,11 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
                                  const float* D, const float* Pr, const float* fsmall, const double* stats,
                                  const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* part,
                                  float* dx, float* dwmix, void* stream) {
-    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part || !dx)
+    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part)
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
+    if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (!dx && d.mode != TFNAS_MODE_STEM) return TFNAS_ENULL;     // the stem's input is the image: no dx
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
@@ -146,7 +158,33 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
-    TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, s));       // dx = de W_expand (+ residual)
+    if (d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, s));   // dx = de W_expand (+ residual)
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
+    return 0;
+}
+
+extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E, double* stats, float* part,
+                              float* pooled, void* stream) {
+    if (!dp || !x || !E || !stats || !part || !pooled) return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    hipStream_t s = S(stream);
+    TRY(launch_expand_fwd(d, x, E, stats, part, s));          // 1x1 conv 320->1280 + BN statistics
+    TRY(launch_head_pool(d, E, stats, pooled, s));            // BN + swish + global average pool
+    return 0;
+}
+
+extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const float* E, const double* stats,
+                              const float* dpooled, float* dEh, float* cb1, double* red, float* part, float* dx,
+                              void* stream) {
+    if (!dp || !x || !E || !stats || !dpooled || !dEh || !cb1 || !red || !part || !dx) return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (d.need_wgrad && !d.g[0].g_expand) return TFNAS_ENULL;
+    hipStream_t s = S(stream);
+    TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));       // pool + swish backward, BN-backward sums
+    TRY(launch_bn1_consts(d, stats, red, cb1, s));
+    TRY(launch_expand_dgrad(d, dEh, E, cb1, nullptr, nullptr, dx, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }

@@ -8,10 +8,29 @@
 #include "kernels.h"
 #include "prof.h"
 
+// ---------------------------------------------------------------------------- stem im2col operand
+// TFNAS_MODE_STEM: the "expand" is first_stem's 3x3 stride-2 pad-1 convolution of the 3-channel NCHW image
+// (models/model_search.py:219).  It runs through the same GEMM kernels with a gathering operand loader:
+// A(p, t) = img[n][t/9][2*ho + (t%9)/3 - 1][2*wo + t%3 - 1]  (t < 27 = im2col depth, OIHW weight order).
+__device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, const TfnasCellDesc& d, int p, int t0) {
+    const int HW = d.H * d.W, n = p / HW, r = p - n * HW, ho = r / d.W, wo = r - ho * d.W;
+    f32x4 v = zero4();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + j;
+        if (t < 27) {
+            const int ci = t / 9, rem = t - 9 * ci, ky = rem / 3, kx = rem - 3 * ky;
+            const int hi = 2 * ho + ky - 1, wi = 2 * wo + kx - 1;
+            if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) v[j] = img[((size_t)(n * 3 + ci) * d.Hi + hi) * d.Wi + wi];
+        }
+    }
+    return v;
+}
+
 // ============================================================================ expand forward
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
-template <int NT>
+template <int NT, bool STEM>
 __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
                                                     float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
@@ -38,11 +57,12 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
         acc_zero<NT>(acc);
         auto fa = [&](int c, int row, int kl) -> f32x4 {
             const int p = rt * 128 + row, k = c * 16 + kl;
-            return (p < P && k < ic) ? ld4(x + (size_t)p * ic + k) : zero4();
+            if (p >= P || k >= ic) return zero4();
+            return STEM ? stem_patch4(x, d, p, k) : ld4(x + (size_t)p * ic + k);
         };
         auto fb = [&](int c, int n, int kl) -> f32x4 {
             const int col = n0 + n, k = c * 16 + kl;
-            return (col < mc && k < ic) ? ld4(w + (size_t)col * ic + k) : zero4();
+            return (col < mc) ? ld4_guard(w + (size_t)col * ic, k, ic, !STEM) : zero4();
         };
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
 #pragma unroll
@@ -374,7 +394,7 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
 
 // ============================================================================ expand wgrad (TN, split-K)
 // part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]   (k_reduce_rows sums the splits)
-template <int NT>
+template <int NT, bool STEM>
 __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ E, const float* __restrict__ cb1,
                                                       const float* __restrict__ x, int rows_per_split,
@@ -413,7 +433,8 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
     };
     auto fb = [&](int c, int kl, int n) -> f32x4 {
         const int p = r0 + c * 16 + kl, cc = n0 + n;
-        return (p < r1 && cc < ic) ? ld4(x + (size_t)p * ic + cc) : zero4();
+        if (p >= r1 || cc >= ic) return zero4();
+        return STEM ? stem_patch4(x, d, p, cc) : ld4(x + (size_t)p * ic + cc);
     };
     gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
 #pragma unroll
@@ -465,7 +486,10 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles, TFNAS_PART_FLOATS / (2 * (size_t)d.M)), tiles);
-    hipLaunchKernelGGL(k_expand_fwd<NT>, grid, dim3(256), 0, s, d, x, E, part);
+    if (d.mode == TFNAS_MODE_STEM)
+        hipLaunchKernelGGL((k_expand_fwd<NT, true>), grid, dim3(256), 0, s, d, x, E, part);
+    else
+        hipLaunchKernelGGL((k_expand_fwd<NT, false>), grid, dim3(256), 0, s, d, x, E, part);
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
@@ -561,7 +585,10 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
     const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size);
     dim3 grid(cdiv(P, rps), mtiles, ntiles);
     DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_wgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
+        if (d.mode == TFNAS_MODE_STEM)
+            hipLaunchKernelGGL((k_expand_wgrad<NT, true>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
+        else
+            hipLaunchKernelGGL((k_expand_wgrad<NT, false>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
     })
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {

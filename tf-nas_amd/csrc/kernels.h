@@ -44,6 +44,9 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gat
                     const float* hpre, const float* pooled, hipStream_t s);
 int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
                    const float* dpooled, double* red2, float* part, hipStream_t s);
+int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats1, float* pooled, hipStream_t s);
+int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1, const float* dpooled, float* dEh,
+                    double* red1, float* part, hipStream_t s);
 // out[c] = sum_{b<nb} part[b*stride + c]  (double and/or float output); the deterministic replacement of atomics
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s);

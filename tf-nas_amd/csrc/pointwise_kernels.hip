@@ -283,6 +283,77 @@ __global__ void k_bn1_consts(TfnasCellDesc d, const double* __restrict__ stats1,
     reinterpret_cast<f32x4*>(cb1)[c] = t;
 }
 
+// ============================================================================ network head (TFNAS_MODE_HEAD)
+// pooled[n][c] = mean_hw act(BN1(E[n][hw][c]))     (feature_mix BN + swish + AdaptiveAvgPool2d(1))
+template <int ACT>
+__global__ __launch_bounds__(256) void k_head_pool(TfnasCellDesc d, const float* __restrict__ E,
+                                                   const double* __restrict__ stats1, float* __restrict__ pooled) {
+    __shared__ f32x4 buf[256];
+    const int mc = d.g[0].mc, mcp = d.g[0].mcp, M = d.M, HW = d.H * d.W, n = blockIdx.x;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = blockIdx.y * 64 + 4 * cq;
+    const bool active = ch < mcp;
+    float2 c1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c1[j] = (active && ch + j < mc) ? bn_consts(stats1 + 2 * (size_t)(ch + j), 1.0 / ((double)d.N * HW), d.eps)
+                                        : make_float2(0.f, 0.f);
+    f32x4 acc = zero4();
+    if (active)
+        for (int hw = rl; hw < HW; hw += 16) {
+            f32x4 v = ld4(E + ((size_t)n * HW + hw) * M + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c1[j].x) * c1[j].y);
+            acc += v;
+        }
+    acc = reduce_rows(acc, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) st4(pooled + (size_t)n * mc + ch, acc * splat4(1.f / (float)HW));
+}
+
+// dEh[p][c] = dpooled[n][c]/HW * act'(ehat) ; per-workgroup partial BN1-backward sums (T1, T2) -> part
+template <int ACT>
+__global__ __launch_bounds__(256) void k_head_bwd(TfnasCellDesc d, const float* __restrict__ E,
+                                                  const double* __restrict__ stats1, const float* __restrict__ dpooled,
+                                                  float* __restrict__ dEh, float* __restrict__ part) {
+    __shared__ f32x4 buf[256];
+    const int mc = d.g[0].mc, mcp = d.g[0].mcp, M = d.M, HW = d.H * d.W, n = blockIdx.x;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = blockIdx.y * 64 + 4 * cq;
+    const bool active = ch < mcp;
+    float2 c1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c1[j] = (active && ch + j < mc) ? bn_consts(stats1 + 2 * (size_t)(ch + j), 1.0 / ((double)d.N * HW), d.eps)
+                                        : make_float2(0.f, 0.f);
+    f32x4 t1 = zero4(), t2 = zero4();
+    if (active) {
+        const f32x4 dp = ld4(dpooled + (size_t)n * mc + ch) * splat4(1.f / (float)HW);
+        for (int hw = rl; hw < HW; hw += 16) {
+            const size_t a = ((size_t)n * HW + hw) * M + ch;
+            const f32x4 e = ld4(E + a);
+            f32x4 deh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float eh = (e[j] - c1[j].x) * c1[j].y;
+                deh[j] = dp[j] * act_d<ACT>(eh);
+                t1[j] += deh[j];
+                t2[j] += deh[j] * eh;
+            }
+            st4(dEh + a, deh);
+        }
+    }
+    t1 = reduce_rows(t1, buf, rl, cq, 16, 16, active);
+    t2 = reduce_rows(t2, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) {
+        float* prow = part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)ch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prow[2 * j + 0] = t1[j];
+            prow[2 * j + 1] = t2[j];
+        }
+    }
+}
+
 // ============================================================================ partials -> totals
 // out[c] = sum_{b < nb} part[b*stride + c]   (summed in double; 16 columns x 16 row-lanes per workgroup)
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int nb, int ncols, size_t stride,
@@ -393,6 +464,22 @@ int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const doub
         hipLaunchKernelGGL((k_bn2_bwd<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, gate, dpooled, part, rpb);
     })
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, red2, nullptr, s);
+}
+
+int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats1, float* pooled, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    dim3 grid(d.N, cdiv(d.g[0].mcp, 64));
+    ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_head_pool<ACT>), grid, dim3(256), 0, s, d, E, stats1, pooled); })
+    return (int)hipGetLastError();
+}
+
+int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1, const float* dpooled, float* dEh,
+                    double* red1, float* part, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    if ((size_t)d.N * 2 * d.M > TFNAS_PART_FLOATS) return TFNAS_ERANGE;
+    dim3 grid(d.N, cdiv(d.g[0].mcp, 64));
+    ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_head_bwd<ACT>), grid, dim3(256), 0, s, d, E, stats1, dpooled, dEh, part); })
+    return launch_reduce_rows(part, d.N, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 
 int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,

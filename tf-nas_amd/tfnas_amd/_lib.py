@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libtfnas_hip.so')
 
 MAX_GROUPS, MAX_SINK, MAX_CELLS = 8, 4, 32
 ACT = {'relu': 0, 'swish': 1}
+MODE_CELL, MODE_STEM, MODE_HEAD = 0, 1, 2
 
 _W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e')
 _G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
@@ -24,7 +25,8 @@ class TfnasGroup(C.Structure):
 class TfnasCellDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
                                           'Ho', 'Wo', 'M', 'SE')]
-                + [('eps', C.c_float), ('pad0', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+                + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
+                   ('pad0', C.c_int32), ('pad1', C.c_int32), ('pad2', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
 
 
 class TfnasCellWs(C.Structure):
@@ -42,6 +44,8 @@ _PROTOS = {
     'tfnas_cell_ws': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasCellWs)]),
     'tfnas_mixedop_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 10),
     'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 16),
+    'tfnas_head_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
+    'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 10),
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),

@@ -39,10 +39,11 @@ def _require_cuda(t, what):
 class CellPlan:
     """Host-side description of one MixedOP launch: geometry + which candidate blocks take part."""
 
-    def __init__(self, ic, oc, stride, act, blocks):
+    def __init__(self, ic, oc, stride, act, blocks, mode=_lib.MODE_CELL):
         self.ic, self.oc, self.stride, self.act = ic, oc, stride, act
         self.blocks = list(blocks)                     # MBInvertedResBlock modules (parameter containers)
-        self.has_res = int(ic == oc and stride == 1)
+        self.mode = mode
+        self.has_res = int(mode == _lib.MODE_CELL and ic == oc and stride == 1)
         self._desc_cache = {}
 
     def params(self):
@@ -57,6 +58,9 @@ class CellPlan:
         if hit is None:
             d = TfnasCellDesc()
             d.N, d.H, d.W, d.ic, d.oc, d.stride = N, H, W, self.ic, self.oc, self.stride
+            d.mode = self.mode
+            if self.mode == _lib.MODE_STEM:            # (H, W) given = image size; plan derives the conv output size
+                d.Hi, d.Wi = H, W
             d.act, d.has_res, d.G, d.need_wgrad, d.eps = _lib.ACT[self.act], self.has_res, len(self.blocks), 0, BN_EPS
             for g, b in enumerate(self.blocks):
                 d.g[g].mc, d.g[g].k, d.g[g].se = b.mid_channels, b.kernel_size, b.se_channels
@@ -71,7 +75,7 @@ class CellPlan:
         """Write current weight (and gradient) pointers into the descriptor."""
         i = 0
         for g, b in enumerate(self.blocks):
-            n = 7 if b.se_channels > 0 else 3
+            n = 1 if self.mode == _lib.MODE_HEAD else (7 if b.se_channels > 0 else 3)
             for j, f in enumerate(_lib._W_FIELDS[:n]):
                 setattr(d.g[g], f, params[i + j].data_ptr())
             if grads is not None:
@@ -79,6 +83,59 @@ class CellPlan:
                     setattr(d.g[g], f, grads[i + j].data_ptr())
             i += n
         d.need_wgrad = int(grads is not None)
+
+
+def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
+    """Shared by MixedOpFn (NHWC input) and StemFn (NCHW image): allocate, launch tfnas_mixedop_fwd, save."""
+    d, ws = plan.desc(N, H, W)
+    for p in params:
+        _require_cuda(p, 'MBConv weight')
+        if not p.is_contiguous():
+            raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
+    plan.bind(d, params)
+    dev = xh.device
+    E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+    D = torch.empty(ws.D, device=dev, dtype=torch.float32)
+    Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
+    fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
+    stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
+    part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+    out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
+    if wmix is not None:
+        wmix = wmix.contiguous()
+    check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                       ptr(stats), ptr(part), ptr(out), _stream()), 'tfnas_mixedop_fwd')
+    ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
+    ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
+    return out.permute(0, 3, 1, 2)
+
+
+def _cell_backward(ctx, dout, want_dx):
+    xh, wmix, E, D, Pr, fsmall, stats, *params = ctx.saved_tensors
+    plan = ctx.plan
+    N, H, W = ctx.shape
+    d, ws = plan.desc(N, H, W)
+    dev = xh.device
+    need_w = any(ctx.needs_input_grad[3:])
+    grads = [torch.empty_like(p) for p in params] if need_w else None
+    plan.bind(d, params, grads)
+    douth = _nhwc(dout)
+    dZ = torch.empty(ws.dZ, device=dev, dtype=torch.float32)
+    dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
+    bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
+    red = torch.empty(ws.red, device=dev, dtype=torch.float64)
+    part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+    dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
+    dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
+    check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                       ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
+                                       ptr(part), ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+    d.need_wgrad = 0
+    if MixedOpFn.debug_sink is not None:
+        MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
+    out = [None, None if dx is None else dx.permute(0, 3, 1, 2), dwmix]
+    out.extend(grads if need_w else [None] * len(params))
+    return tuple(out)
 
 
 class MixedOpFn(torch.autograd.Function):
@@ -91,55 +148,74 @@ class MixedOpFn(torch.autograd.Function):
         _require_cuda(x, 'MixedOP input')
         xh = _nhwc(x)
         N, H, W, _ = xh.shape
-        d, ws = plan.desc(N, H, W)
-        for p in params:
-            _require_cuda(p, 'MBConv weight')
-            if not p.is_contiguous():
-                raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
-        plan.bind(d, params)
-        dev = x.device
-        E = torch.empty(ws.E, device=dev, dtype=torch.float32)
-        D = torch.empty(ws.D, device=dev, dtype=torch.float32)
-        Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
-        fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
-        stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
-        out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
-        if wmix is not None:
-            wmix = wmix.contiguous()
-        check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                           ptr(stats), ptr(part), ptr(out), _stream()), 'tfnas_mixedop_fwd')
-        ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
-        ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
-        return out.permute(0, 3, 1, 2)
+        return _cell_forward(ctx, plan, xh, N, H, W, wmix, params)
 
     @staticmethod
     def backward(ctx, dout):
-        xh, wmix, E, D, Pr, fsmall, stats, *params = ctx.saved_tensors
+        return _cell_backward(ctx, dout, True)
+
+
+class StemFn(torch.autograd.Function):
+    """first_stem (conv3x3 s2 3->32 + BN + ReLU) and second_stem (MBConv 32->16, SE 8, no expand) of the reference
+    Network (models/model_search.py:219-220, forward :283-284) as ONE stem cell: the 3x3 convolution of the NCHW
+    image takes the place of the 1x1 expand (TFNAS_MODE_STEM); everything after it is the ordinary cell pipeline.
+    params = (first_stem.conv.weight, second_stem dw / project / SE weights)."""
+
+    @staticmethod
+    def forward(ctx, plan, img, _unused, *params):
+        _require_cuda(img, 'stem input image')
+        x = img.contiguous()                     # NCHW, as the reference's data loader delivers it
+        N, C_, Hi, Wi = x.shape
+        if C_ != 3:
+            raise RuntimeError('tfnas_amd: the stem expects a 3-channel image')
+        return _cell_forward(ctx, plan, x, N, Hi, Wi, None, params)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _cell_backward(ctx, dout, False)
+
+
+class HeadFn(torch.autograd.Function):
+    """pooled[N,1280] = AdaptiveAvgPool2d(1)(swish(BN(conv1x1(x))))  -- feature_mix_layer + global_avg_pooling
+    (models/model_search.py:299-300) via tfnas_head_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, plan, x, w):
+        _require_cuda(x, 'head input')
+        _require_cuda(w, 'feature_mix weight')
+        xh = _nhwc(x)
+        N, H, W, _ = xh.shape
+        d, ws = plan.desc(N, H, W)
+        plan.bind(d, [w])
+        dev = x.device
+        E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+        stats = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        pooled = torch.empty((N, d.g[0].mc), device=dev, dtype=torch.float32)
+        check(_lib.lib().tfnas_head_fwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(part), ptr(pooled), _stream()),
+              'tfnas_head_fwd')
+        ctx.plan, ctx.shape = plan, (N, H, W)
+        ctx.save_for_backward(xh, E, stats, w)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        xh, E, stats, w = ctx.saved_tensors
         plan = ctx.plan
         N, H, W = ctx.shape
         d, ws = plan.desc(N, H, W)
         dev = xh.device
-        need_w = any(ctx.needs_input_grad[3:])
-        grads = [torch.empty_like(p) for p in params] if need_w else None
-        plan.bind(d, params, grads)
-        douth = _nhwc(dout)
-        dZ = torch.empty(ws.dZ, device=dev, dtype=torch.float32)
+        gw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        plan.bind(d, [w], None if gw is None else [gw])
         dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
-        bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
-        red = torch.empty(ws.red, device=dev, dtype=torch.float64)
+        cb1 = torch.empty(4 * d.M, device=dev, dtype=torch.float32)
+        red = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
         part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
-        dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
-        check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                           ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
-                                           ptr(part), ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+        check(_lib.lib().tfnas_head_bwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(dpooled.contiguous()), ptr(dEh),
+                                        ptr(cb1), ptr(red), ptr(part), ptr(dx), _stream()), 'tfnas_head_bwd')
         d.need_wgrad = 0
-        if MixedOpFn.debug_sink is not None:
-            MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
-        out = [None, dx.permute(0, 3, 1, 2), dwmix]
-        out.extend(grads if need_w else [None] * len(params))
-        return tuple(out)
+        return None, dx.permute(0, 3, 1, 2), gw
 
 
 MixedOpFn.debug_sink = None      # tests set this to a list to capture backward scratch tensors

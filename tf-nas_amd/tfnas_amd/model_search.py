@@ -18,7 +18,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functions import ArchFn, CellPlan, MixedOpFn, SinkFn, arch_sample
+from . import _lib
+from .functions import ArchFn, CellPlan, HeadFn, MixedOpFn, SinkFn, StemFn, arch_sample
 from .layers import ConvLayer, LinearLayer, MBInvertedResBlock
 
 PRIMITIVES = [
@@ -219,6 +220,45 @@ class Network(nn.Module):
         self.classifier = LinearLayer(1280, num_classes)
         self._initialization()
         self._cells = None
+        self._stem_plan = None
+        self._head_plan = None
+
+    # ---- stems / head on the HIP path -------------------------------------------------------------------
+    class _StemBlock:
+        """Adapter presenting first_stem.conv + second_stem as one candidate block of a TFNAS_MODE_STEM cell."""
+
+        def __init__(self, first, second):
+            self.first, self.second = first, second
+            self.mid_channels, self.kernel_size, self.se_channels = second.mid_channels, second.kernel_size, second.se_channels
+
+        def hip_params(self):
+            se = self.second.squeeze_excite
+            return [self.first.conv.weight, self.second.depth_conv.conv.weight, self.second.point_linear.conv.weight,
+                    se.conv_reduce.weight, se.conv_reduce.bias, se.conv_expand.weight, se.conv_expand.bias]
+
+    class _HeadBlock:
+        def __init__(self, conv_layer):
+            self.layer = conv_layer
+            self.mid_channels, self.kernel_size, self.se_channels = conv_layer.out_channels, 3, 0
+
+        def hip_params(self):
+            return [self.layer.conv.weight]
+
+    def _stem(self, x):
+        fs, ss = self.first_stem, self.second_stem
+        if (fs.kernel_size, fs.stride, fs.in_channels, fs.act_func, ss.act_func, ss.stride) != (3, 2, 3, 'relu', 'relu', 1) \
+                or ss.inverted_bottleneck is not None or ss.squeeze_excite is None:
+            raise NotImplementedError('stem geometry differs from models/model_search.py:219-220')
+        if self._stem_plan is None:
+            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [Network._StemBlock(fs, ss)], mode=_lib.MODE_STEM)
+        plan = self._stem_plan
+        return StemFn.apply(plan, x, None, *plan.params())
+
+    def _head(self, x):
+        fm = self.feature_mix_layer
+        if self._head_plan is None:
+            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [Network._HeadBlock(fm)], mode=_lib.MODE_HEAD)
+        return HeadFn.apply(self._head_plan, x, fm.conv.weight)
 
     def stages(self):
         return [getattr(self, n) for n in self._stage_names]
@@ -264,20 +304,14 @@ class Network(nn.Module):
 
     def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None):
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
-        # stems use stock PyTorch-ROCm ops in plain NCHW: MIOpen's fp32 NHWC path falls back to naive_conv_*
-        # kernels (368 ms per wgrad at batch 128, profiles/round1_first_kernel_stats.csv); the MixedOP cells
-        # want NHWC, so the (small, 16-channel) stem output is re-laid-out once here.
-        x = x.contiguous()
-        x = self.first_stem(x)
-        x = self.second_stem(x)
-        x = x.contiguous(memory_format=torch.channels_last)
+        # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per
+        # iteration pair here: MIOpen's fp32 NHWC path falls back to naive_conv_*, torch's BN backward is slow)
+        x = self._stem(x)
         self._prepare(x, sampling, mode, exp_noise, rand_pos)
         for st in self.stages():
             x, lat = st(x, sampling, mode)
             out_lat += lat
-        x = self.feature_mix_layer(x)
-        x = self.global_avg_pooling(x)
-        x = x.view(x.size(0), -1)
+        x = self._head(x)                      # feature_mix_layer + global_avg_pooling (HIP), [N, 1280]
         x = self.classifier(x)
         return x, out_lat
 
