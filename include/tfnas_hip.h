@@ -110,6 +110,7 @@ typedef struct TfnasCellWs {
     uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd); reductions are done by a
                           second tiny kernel instead of device-scope atomics -> deterministic results          */
     uint64_t dx;       /* floats  [N*H*W][ic]                                               */
+    uint64_t dxp;      /* floats  split-K partial tiles of the expand dgrad (may be tiny); pass NULL to disable */
 } TfnasCellWs;
 
 int tfnas_abi_version(void);
@@ -140,8 +141,8 @@ int tfnas_mixedop_fwd(const TfnasCellDesc *d, const float *x, const float *wmix,
 int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
                       const float *E, const float *D, const float *Pr, const float *fsmall,
                       const double *stats, const float *dout,
-                      float *dZ, float *dEh, float *bsmall, double *red, float *part,
-                      float *dx, float *dwmix, void *stream);
+                      float *dZ, float *dEh, float *bsmall, double *red, float *part, /* then: dx, dxp, dwmix */
+                      float *dx, float *dxp, float *dwmix, void *stream);
 
 /* Network head (mode TFNAS_MODE_HEAD): pooled[N][mc] = mean over pixels of act(BN(x W_expand^T)).
  * Replaces feature_mix_layer (ConvLayer 1x1 + BN + swish) + AdaptiveAvgPool2d(1), models/model_search.py:299-300.
@@ -151,7 +152,7 @@ int tfnas_head_fwd(const TfnasCellDesc *d, const float *x, float *E, double *sta
 /* Backward of tfnas_head_fwd: dx [N*H*W][ic] and (need_wgrad) g_expand.  dEh [N*H*W][M], cb1 [M][4] floats and
  * red doubles [M][2] are scratch. */
 int tfnas_head_bwd(const TfnasCellDesc *d, const float *x, const float *E, const double *stats, const float *dpooled,
-                   float *dEh, float *cb1, double *red, float *part, float *dx, void *stream);
+                   float *dEh, float *cb1, double *red, float *part, float *dx, float *dxp, void *stream);
 
 /* Gumbel-softmax over the candidates of `ncell` cells in one launch + expected cell latency.
  *   w[c][i] = softmax_i((log_alpha[c][i] - log(e[c][i])) / T)      (F.gumbel_softmax, model_search.py:87)

@@ -81,6 +81,10 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->red = ws->off_red1 + 2 * M;
     ws->part = TFNAS_PART_FLOATS;
     ws->dx = P * d->ic;
+    {
+        const int ns = d->mode == TFNAS_MODE_STEM ? 1 : expand_dgrad_splits(*d);
+        ws->dxp = ns > 1 ? (uint64_t)ns * P * d->ic : 4;   /* split-K partials of the expand dgrad */
+    }
     return 0;
 }
 
@@ -116,7 +120,7 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
 extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const float* wmix, const float* E,
                                  const float* D, const float* Pr, const float* fsmall, const double* stats,
                                  const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* part,
-                                 float* dx, float* dwmix, void* stream) {
+                                 float* dx, float* dxp, float* dwmix, void* stream) {
     if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part)
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
@@ -158,7 +162,7 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
-    if (d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, s));   // dx = de W_expand (+ residual)
+    if (d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }
@@ -176,7 +180,7 @@ extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E,
 
 extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const float* E, const double* stats,
                               const float* dpooled, float* dEh, float* cb1, double* red, float* part, float* dx,
-                              void* stream) {
+                              float* dxp, void* stream) {
     if (!dp || !x || !E || !stats || !dpooled || !dEh || !cb1 || !red || !part || !dx) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
@@ -184,7 +188,7 @@ extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const flo
     hipStream_t s = S(stream);
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));       // pool + swish backward, BN-backward sums
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
-    TRY(launch_expand_dgrad(d, dEh, E, cb1, nullptr, nullptr, dx, s));
+    TRY(launch_expand_dgrad(d, dEh, E, cb1, nullptr, nullptr, dx, dxp, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }

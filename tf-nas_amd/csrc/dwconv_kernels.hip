@@ -72,6 +72,37 @@ __device__ __forceinline__ void stage_weights(float* wts, const float* __restric
 // Cooperative load of an [L0 x L1] pixel tile x CC channels into LDS (layout [pix][CC]).
 // fetch(pix_row, pix_col, cq, ok) -> f32x4 is called only to build the value AFTER the raw loads were issued:
 //   addr(r, c, cq, valid&) returns the element offset; xf(v, cq) transforms the loaded vector.
+// two-source variant: both sources share the addressing; xf(v0, v1, cq) combines them (8 loads in flight)
+template <class FAddr, class FXf>
+__device__ __forceinline__ void load_tile2(float* tile, int L0, int L1, int CC, int cq_shift,
+                                           const float* __restrict__ src0, const float* __restrict__ src1, FAddr addr,
+                                           FXf xf) {
+    const int CQ = CC >> 2, total = L0 * L1 * CQ;
+    const float inv_l1 = 1.f / (float)L1;
+    for (int base = 0; base < total; base += 1024) {
+        f32x4 v0[4], v1[4];
+        int pix[4], cqv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            pix[u] = idx >> cq_shift;
+            cqv[u] = idx & (CQ - 1);
+            const int r = (int)(((float)pix[u] + 0.5f) * inv_l1);
+            const int c = pix[u] - r * L1;
+            size_t a = 0;
+            ok[u] = idx < total && addr(r, c, cqv[u], a);
+            v0[u] = ok[u] ? ld4(src0 + a) : zero4();
+            v1[u] = ok[u] ? ld4(src1 + a) : zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            if (idx < total) st4(tile + pix[u] * CC + 4 * cqv[u], ok[u] ? xf(v0[u], v1[u], cqv[u]) : zero4());
+        }
+    }
+}
+
 template <class FAddr, class FXf>
 __device__ __forceinline__ void load_tile(float* tile, int L0, int L1, int CC, int cq_shift, const float* __restrict__ src,
                                           FAddr addr, FXf xf) {
@@ -250,42 +281,13 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
         const int hi0 = th * TIH, wi0 = tw * TIW;
         const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
         __syncthreads();
-        load_tile(dd_tile, OH, OW, CC, gm.cq_shift, ddh,
-                  [&](int r, int c, int cq, size_t& a) {
-                      const int ho = oh0 + r, wo = ow0 + c;
-                      a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-                      return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
-                  },
-                  [&](f32x4 v, int cq) { return v; });
-        // second operand of the BN2-backward transform: D at the same positions (read-modify the LDS tile)
-        __syncthreads();
-        {
-            const int total = OH * OW * CQ;
-            const float inv_l1 = 1.f / (float)OW;
-            for (int base = 0; base < total; base += 1024) {
-                f32x4 v[4];
-                int pix[4], cqv[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = base + u * 256 + tid;
-                    pix[u] = idx >> gm.cq_shift;
-                    cqv[u] = idx & (CQ - 1);
-                    const int r = (int)(((float)pix[u] + 0.5f) * inv_l1);
-                    const int c = pix[u] - r * OW;
-                    const int ho = oh0 + r, wo = ow0 + c;
-                    ok[u] = idx < total && ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cqv[u] < mcp;
-                    v[u] = ok[u] ? ld4(D + ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cqv[u]) : zero4();
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (ok[u]) {
-                        float* p = dd_tile + pix[u] * CC + 4 * cqv[u];
-                        st4(p, bn2_dd(cst2, 4 * cqv[u], ld4(p), v[u]));
-                    }
-                }
-            }
-        }
+        load_tile2(dd_tile, OH, OW, CC, gm.cq_shift, ddh, D,
+                   [&](int r, int c, int cq, size_t& a) {
+                       const int ho = oh0 + r, wo = ow0 + c;
+                       a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
+                       return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
+                   },
+                   [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd(cst2, 4 * cq, v, dv); });
         __syncthreads();
 
         for (int item = tid; item < nstrips * CQ; item += 256) {
@@ -529,6 +531,7 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
     }
     const size_t cap = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
     if ((size_t)gx > cap) gx = (int)cap;
+    if (gx > 256) gx = 256;                        // partial rows to reduce afterwards
     return gx < 1 ? 1 : gx;
 }
 

@@ -176,6 +176,36 @@ __device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], f
     __syncthreads();
 }
 
+// Emit the 128 x BN accumulator tile as 16-byte pieces of rows: emit(local_row, local_col (multiple of 4), f32x4).
+// The MFMA C layout gives a lane 4 rows x 1 column per 16x16 tile, so a direct store writes 64-byte row segments;
+// staging 16 rows per wave through LDS turns that into whole contiguous row pieces (256 B per row at BN = 64).
+template <int NT, class FEmit>
+__device__ __forceinline__ void emit_tile_rows(const f32x4 (&acc)[2][NT], float* lds, FEmit emit) {
+    using T = GT<NT>;
+    constexpr int LDC = T::BN + 4, Q = T::BN / 4;
+    static_assert(4 * 16 * LDC <= T::LDS_FLOATS, "C staging does not fit the GEMM LDS buffer");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    float* st = lds + w * 16 * LDC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(4 * lq + r) * LDC + 16 * j + lr] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (16 * Q + 63) / 64; ++it) {
+            const int idx = it * 64 + lane;
+            if (idx < 16 * Q) {
+                const int row = idx / Q, c4 = idx - row * Q;
+                emit(w * 32 + 16 * i + row, 4 * c4, ld4(st + row * LDC + 4 * c4));
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // NT choice for an N extent: minimise padded columns, prefer the wider tile on ties.
 static inline int pick_nt(int n, const int* cands, int ncand) {
     int best = cands[0];

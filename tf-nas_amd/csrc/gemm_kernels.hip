@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
     const int n0 = ty * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7, nchunks = (ic + 15) >> 4;
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    const int tid = threadIdx.x;
+    (void)tid;
 
     float cs[NT], cq[NT];
 #pragma unroll
@@ -65,18 +66,10 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
             return (col < mc) ? ld4_guard(w + (size_t)col * ic, k, ic, !STEM) : zero4();
         };
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
-                if (p < P) {
-                    float* dst = E + (size_t)p * M + off + n0 + lr;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        if (n0 + 16 * j + lr < mcp) dst[16 * j] = acc[i][j][r];
-                }
-            }
+        emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
+            const int p = rt * 128 + lrow;
+            if (p < P && n0 + lc < mcp) st4(E + (size_t)p * M + off + n0 + lc, v);
+        });
         acc_colstats<NT>(acc, cs, cq);
     }
     flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp);
@@ -99,7 +92,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const floa
     const int n0 = blockIdx.y * T::BN;
     const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
     const int nrt = (Po + 127) >> 7, nchunks = (mcp + 15) >> 4;
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    const int tid = threadIdx.x;
 
     float2* cst = reinterpret_cast<float2*>(lds + T::LDS_FLOATS);
     for (int c = tid; c < ((mcp + 15) & ~15); c += 256)
@@ -130,18 +123,10 @@ __global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const floa
             return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, w_al) : zero4();
         };
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
-                if (p < Po) {
-                    float* dst = Pr + ((size_t)g * Po + p) * oc + n0 + lr;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        if (n0 + 16 * j + lr < oc) dst[16 * j] = acc[i][j][r];
-                }
-            }
+        emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
+            const int p = rt * 128 + lrow;
+            if (p < Po && n0 + lc < oc) st4(Pr + ((size_t)g * Po + p) * oc + n0 + lc, v);
+        });
         acc_colstats<NT>(acc, cs, cq);
     }
     flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
@@ -206,7 +191,8 @@ __global__ __launch_bounds__(256) void k_project_dgrad(TfnasCellDesc d, const fl
     const int Po = d.N * d.Ho * d.Wo, oc = d.oc, M = d.M;
     const int ocp = (oc + 15) & ~15;
     const int nrt = (Po + 127) >> 7, nchunks = ocp >> 4;
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    const int tid = threadIdx.x;
+    (void)tid;
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
     __syncthreads();
@@ -224,18 +210,10 @@ __global__ __launch_bounds__(256) void k_project_dgrad(TfnasCellDesc d, const fl
             return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, w_al) : zero4();
         };
         gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
-                if (p < Po) {
-                    float* dst = dZ + (size_t)p * M + off + n0 + lr;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        if (n0 + 16 * j + lr < mcp) dst[16 * j] = acc[i][j][r];
-                }
-            }
+        emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
+            const int p = rt * 128 + lrow;
+            if (p < Po && n0 + lc < mcp) st4(dZ + (size_t)p * M + off + n0 + lc, v);
+        });
     }
 }
 
@@ -325,19 +303,26 @@ __device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
 
 // ============================================================================ expand dgrad
 // dx[p][c] = sum_g sum_m de[p][off_g+m] * w_expand_g[m][c]  (+ sumw * dout[p][c] for residual cells)
+// K (= all mid channels of all groups, up to 6912) is split over blockIdx.z when the output grid alone cannot fill the
+// chip (7x7 / 14x14 cells: 49..196 row tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them.
 template <int NT>
 __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ E, const float* __restrict__ cb1,
                                                       const float* __restrict__ dout,
-                                                      const float* __restrict__ wmix, float* __restrict__ dx) {
+                                                      const float* __restrict__ wmix, float* __restrict__ dx,
+                                                      float* __restrict__ dxp, int nsplit) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     const int n0 = blockIdx.y * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7;
-    int nchunks = 0;
-    for (int g = 0; g < d.G; ++g) nchunks += (d.g[g].mcp + 15) >> 4;
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    int nchunks_all = 0;
+    for (int g = 0; g < d.G; ++g) nchunks_all += (d.g[g].mcp + 15) >> 4;
+    const int per = (nchunks_all + nsplit - 1) / nsplit;
+    const int cbeg = blockIdx.z * per;
+    const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
+    float* __restrict__ dst = nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx;
+    const bool add_res = d.has_res && nsplit == 1;
     float sumw = 1.f;
     if (wmix) {
         sumw = 0.f;
@@ -349,6 +334,7 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
         auto locate = [&](int c, int& g, int& k0) {
+            c += cbeg;
             g = 0;
             for (; g < d.G - 1; ++g) {
                 const int t = (d.g[g].mcp + 15) >> 4;
@@ -372,23 +358,30 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
             return (k < d.g[g].mc && n0 + n < ic) ? ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
         };
         gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = rt * 128 + wrow + 16 * i + 4 * lq + r;
-                if (p < P) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int c = n0 + 16 * j + lr;
-                        if (c < ic) {
-                            float v = acc[i][j][r];
-                            if (d.has_res) v += sumw * dout[(size_t)p * d.oc + c];
-                            dx[(size_t)p * ic + c] = v;
-                        }
-                    }
-                }
+        emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
+            const int p = rt * 128 + lrow, c = n0 + lc;
+            if (p < P && c < ic) {
+                if (add_res) v += splat4(sumw) * ld4(dout + (size_t)p * d.oc + c);
+                st4(dst + (size_t)p * ic + c, v);
             }
+        });
+    }
+}
+
+// dx = sum_z dxp[z] (+ sumw * dout for residual cells)
+__global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float* __restrict__ dxp, int nsplit,
+                                                   const float* __restrict__ dout, const float* __restrict__ wmix,
+                                                   float* __restrict__ dx) {
+    const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
+    float sumw = 1.f;
+    if (wmix) {
+        sumw = 0.f;
+        for (int g = 0; g < d.G; ++g) sumw += wmix[g];
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = d.has_res ? splat4(sumw) * ld4(dout + 4 * i) : zero4();
+        for (int z = 0; z < nsplit; ++z) v += ld4(dxp + (size_t)z * n4 * 4 + 4 * i);
+        st4(dx + 4 * i, v);
     }
 }
 
@@ -469,6 +462,12 @@ static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channe
     if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; } \
     else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
 
+// kernels with a statistics epilogue: at most 256 partial rows (keeps k_reduce_rows short) and they must fit
+static size_t stats_row_cap(size_t row_floats) {
+    const size_t fit = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
+    return fit < 256 ? fit : 256;
+}
+
 // number of persistent row-blocks: ~4096 workgroups in total, and (for kernels with a statistics epilogue)
 // at most `cap` so that the per-workgroup partials fit the scratch buffer
 static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30) {
@@ -485,7 +484,7 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     constexpr int NT = 4;
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, TFNAS_PART_FLOATS / (2 * (size_t)d.M)), tiles);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M)), tiles);
     if (d.mode == TFNAS_MODE_STEM)
         hipLaunchKernelGGL((k_expand_fwd<NT, true>), grid, dim3(256), 0, s, d, x, E, part);
     else
@@ -501,7 +500,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int tiles = cdiv(d.oc, 16 * nt);
     const int ncols2 = 2 * d.G * d.oc;
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, TFNAS_PART_FLOATS / (size_t)ncols2), tiles, d.G);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, stats_row_cap((size_t)ncols2)), tiles, d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part);
@@ -560,15 +559,35 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
     return (int)hipGetLastError();
 }
 
+// K-splits of expand dgrad: only when the (row tile x column tile) grid cannot fill the chip
+int expand_dgrad_splits(const TfnasCellDesc& d) {
+    const int nt = pick_nt(d.ic, kNtSmall, 6);
+    const int tiles = cdiv(d.N * d.H * d.W, 128) * cdiv(d.ic, 16 * nt);
+    if (tiles >= 512) return 1;
+    int nchunks = 0;
+    for (int g = 0; g < d.G; ++g) nchunks += cdiv(d.g[g].mcp, 16);
+    int ns = cdiv(1024, tiles);
+    if (ns > 16) ns = 16;
+    if (ns > nchunks / 4) ns = nchunks / 4;      // at least 4 K-chunks per split
+    return ns < 1 ? 1 : ns;
+}
+
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
-                        const float* dout, const float* wmix, float* dx, hipStream_t s) {
+                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s) {
     ProfScope _prof(TK_EXPAND_DGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles), tiles);
+    const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit), tiles, nsplit);
     DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, dout, wmix, dx);
+        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, dout, wmix, dx, dxp, nsplit);
     })
+    if (nsplit > 1) {
+        const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
+        size_t blocks = cdiv64(n4, 256 * 2);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, dout, wmix, dx);
+    }
     return (int)hipGetLastError();
 }
 

@@ -14,7 +14,8 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s);
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
-                        const float* dout, const float* wmix, float* dx, hipStream_t s);
+                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s);
+int expand_dgrad_splits(const TfnasCellDesc& d);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s);
 

@@ -363,11 +363,12 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
     const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
     if (c < ncols) {
-        for (int b = rl; b < nb; b += 64) {
-            float v[4];
+        for (int b = rl; b < nb; b += 256) {          // 16 independent loads in flight per thread (nb <= 256 typ.)
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (b + 16 * u < nb) ? part[(size_t)(b + 16 * u) * stride + c] : 0.f;
-            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            for (int u = 0; u < 16; ++u) v[u] = (b + 16 * u < nb) ? part[(size_t)(b + 16 * u) * stride + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
         }
     }
     buf[rl][cl] = s;
@@ -432,7 +433,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
     ProfScope _prof(TK_MIX_BWD_STATS, s);
     const int Po = d.N * d.Ho * d.Wo;
     const int ncols = 2 * d.G * d.oc + d.oc;       // (S1,S2) pairs + per-channel <dout,x>; reduced into red3|resdot
-    size_t nblk = 1024;
+    size_t nblk = 512;
     if (nblk > TFNAS_PART_FLOATS / (size_t)ncols) nblk = TFNAS_PART_FLOATS / (size_t)ncols;
     int rpb = cdiv(Po, (int)nblk);
     const int RP = 256 / (d.oc / 4);
@@ -455,6 +456,7 @@ int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const doub
     const int Po = d.N * d.Ho * d.Wo;
     const int chunks = chunk_count(d, 64, false);
     int want = cdiv(4096, chunks);
+    if (want > 256) want = 256;                    // partial rows to reduce afterwards
     const size_t cap = TFNAS_PART_FLOATS / (2 * (size_t)d.M);
     if ((size_t)want > cap) want = (int)cap;
     int rpb = cdiv(Po, want < 1 ? 1 : want);

@@ -33,7 +33,7 @@ class TfnasCellWs(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         'E', 'D', 'Pr', 'fsmall', 'off_pooled', 'off_gate', 'off_hpre', 'stats', 'off_stats1', 'off_stats2',
         'off_stats3', 'out', 'dZ', 'dEh', 'bsmall', 'off_dgate', 'off_dpooled', 'off_dgl', 'off_dhpre', 'off_cb1',
-        'red', 'off_red3', 'off_red2', 'off_red1', 'off_resdot', 'part', 'dx')]
+        'red', 'off_red3', 'off_red2', 'off_red1', 'off_resdot', 'part', 'dx', 'dxp')]
 
 
 _P = C.c_void_p
@@ -43,9 +43,9 @@ _PROTOS = {
     'tfnas_cell_plan': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_cell_ws': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasCellWs)]),
     'tfnas_mixedop_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 10),
-    'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 16),
+    'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 17),
     'tfnas_head_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
-    'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 10),
+    'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),

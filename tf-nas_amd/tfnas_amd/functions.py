@@ -126,10 +126,11 @@ def _cell_backward(ctx, dout, want_dx):
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
     part = torch.empty(ws.part, device=dev, dtype=torch.float32)
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
+    dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
     check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                        ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
-                                       ptr(part), ptr(dx), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+                                       ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
     d.need_wgrad = 0
     if MixedOpFn.debug_sink is not None:
         MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
@@ -212,8 +213,9 @@ class HeadFn(torch.autograd.Function):
         red = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
         part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
+        dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32)
         check(_lib.lib().tfnas_head_bwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(dpooled.contiguous()), ptr(dEh),
-                                        ptr(cb1), ptr(red), ptr(part), ptr(dx), _stream()), 'tfnas_head_bwd')
+                                        ptr(cb1), ptr(red), ptr(part), ptr(dx), ptr(dxp), _stream()), 'tfnas_head_bwd')
         d.need_wgrad = 0
         return None, dx.permute(0, 3, 1, 2), gw
 
