@@ -98,8 +98,10 @@ def run_gpu(args):
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    launched = 'RANK' in os.environ            # under torch.distributed.run: always bring RCCL up (also at N=1)
+    if world > 1 or launched:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     B = args.batch
     torch.manual_seed(2)
@@ -145,7 +147,7 @@ def run_gpu(args):
     lib.tfnas_prof_enable(1 << names.index(dominant))               # only the dominant family in the timed region
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +157,7 @@ def run_gpu(args):
         pair(args.warmup + 1 + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -193,7 +195,7 @@ def run_gpu(args):
                       roofline=roof,
                       kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
                                           if v[0]})
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return result
 

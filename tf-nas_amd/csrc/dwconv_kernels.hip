@@ -531,7 +531,7 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
     }
     const size_t cap = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
     if ((size_t)gx > cap) gx = (int)cap;
-    if (gx > 256) gx = 256;                        // partial rows to reduce afterwards
+    if (gx > 1024) gx = 1024;                      // partial rows to reduce afterwards
     return gx < 1 ? 1 : gx;
 }
 

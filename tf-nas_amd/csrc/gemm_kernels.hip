@@ -462,10 +462,10 @@ static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channe
     if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; } \
     else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
 
-// kernels with a statistics epilogue: at most 256 partial rows (keeps k_reduce_rows short) and they must fit
+// kernels with a statistics epilogue: at most 1024 partial rows (k_reduce_rows folds 512 per round trip) and they must fit
 static size_t stats_row_cap(size_t row_floats) {
     const size_t fit = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
-    return fit < 256 ? fit : 256;
+    return fit < 1024 ? fit : 1024;
 }
 
 // number of persistent row-blocks: ~4096 workgroups in total, and (for kernels with a statistics epilogue)

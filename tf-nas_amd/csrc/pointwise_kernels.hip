@@ -355,18 +355,19 @@ __global__ __launch_bounds__(256) void k_head_bwd(TfnasCellDesc d, const float* 
 }
 
 // ============================================================================ partials -> totals
-// out[c] = sum_{b < nb} part[b*stride + c]   (summed in double; 16 columns x 16 row-lanes per workgroup)
+// out[c] = sum_{b < nb} part[b*stride + c]   (summed in double; 8 columns x 32 row-lanes per workgroup, 16 loads in
+// flight per thread, so up to 512 partial rows are folded in one round trip)
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int nb, int ncols, size_t stride,
                                                      double* __restrict__ out_d, float* __restrict__ out_f) {
-    __shared__ double buf[16][17];
-    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double buf[32][9];
+    const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0;
     if (c < ncols) {
-        for (int b = rl; b < nb; b += 256) {          // 16 independent loads in flight per thread (nb <= 256 typ.)
+        for (int b = rl; b < nb; b += 512) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (b + 16 * u < nb) ? part[(size_t)(b + 16 * u) * stride + c] : 0.f;
+            for (int u = 0; u < 16; ++u) v[u] = (b + 32 * u < nb) ? part[(size_t)(b + 32 * u) * stride + c] : 0.f;
 #pragma unroll
             for (int u = 0; u < 16; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
         }
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
     if (rl == 0 && c < ncols) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += buf[r][cl];
+        for (int r = 0; r < 32; ++r) t += buf[r][cl];
         if (out_d) out_d[c] = t;
         if (out_f) out_f[c] = (float)t;
     }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
 
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(ncols, 16)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(ncols, 8)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
     return (int)hipGetLastError();
 }
 
@@ -433,7 +434,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
     ProfScope _prof(TK_MIX_BWD_STATS, s);
     const int Po = d.N * d.Ho * d.Wo;
     const int ncols = 2 * d.G * d.oc + d.oc;       // (S1,S2) pairs + per-channel <dout,x>; reduced into red3|resdot
-    size_t nblk = 512;
+    size_t nblk = 1024;
     if (nblk > TFNAS_PART_FLOATS / (size_t)ncols) nblk = TFNAS_PART_FLOATS / (size_t)ncols;
     int rpb = cdiv(Po, (int)nblk);
     const int RP = 256 / (d.oc / 4);
@@ -456,7 +457,7 @@ int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const doub
     const int Po = d.N * d.Ho * d.Wo;
     const int chunks = chunk_count(d, 64, false);
     int want = cdiv(4096, chunks);
-    if (want > 256) want = 256;                    // partial rows to reduce afterwards
+    if (want > 1024) want = 1024;                  // partial rows to reduce afterwards
     const size_t cap = TFNAS_PART_FLOATS / (2 * (size_t)d.M);
     if ((size_t)want > cap) want = (int)cap;
     int rpb = cdiv(Po, want < 1 ? 1 : want);

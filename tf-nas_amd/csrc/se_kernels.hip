@@ -140,24 +140,46 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
 }
 
 // bias gradients: gb_se_e[c] = sum_n dgl[n][c] ; gb_se_r[j] = sum_n dhpre[n][j]
+// 64 columns x 4 batch-lanes per workgroup, 8 loads in flight per thread
 __global__ __launch_bounds__(256) void k_se_bias_grad(TfnasCellDesc d, SeArgs a) {
+    __shared__ float buf[4][64];
     const int g = se_group_idx(d, blockIdx.y);
     if (g < 0) return;
     const int mc = d.g[g].mc, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
     const int N = d.N, M = d.M, SE = d.SE;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cl;
+    float s = 0.f;
     if (idx < mc) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float gt = a.gate[(size_t)n * M + off + idx];
-            s += a.dgate[(size_t)n * M + off + idx] * gt * (1.f - gt);
+        for (int n0 = nl; n0 < N; n0 += 32) {
+            float gt[8], dg[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + 4 * u < N ? n0 + 4 * u : 0;
+                gt[u] = a.gate[(size_t)n * M + off + idx];
+                dg[u] = a.dgate[(size_t)n * M + off + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (n0 + 4 * u < N) s += dg[u] * gt[u] * (1.f - gt[u]);
         }
-        d.g[g].gb_se_e[idx] = s;
     } else if (idx < mc + se) {
         const int j = idx - mc;
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += a.dhpre[(size_t)n * SE + so + j];
-        d.g[g].gb_se_r[j] = s;
+        for (int n0 = nl; n0 < N; n0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.dhpre[(size_t)(n0 + 4 * u < N ? n0 + 4 * u : 0) * SE + so + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (n0 + 4 * u < N) s += v[u];
+        }
+    }
+    buf[nl][cl] = s;
+    __syncthreads();
+    if (nl == 0) {
+        const float t = (buf[0][cl] + buf[1][cl]) + (buf[2][cl] + buf[3][cl]);
+        if (idx < mc) d.g[g].gb_se_e[idx] = t;
+        else if (idx < mc + se) d.g[g].gb_se_r[idx - mc] = t;
     }
 }
 
@@ -218,6 +240,6 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gat
     SeArgs a = {pooled, gate, hpre, dgate, dhpre, nullptr};
     SE_LAUNCH(4, mcp_max, se_max)
     SE_LAUNCH(5, mcp_max, se_max)
-    hipLaunchKernelGGL(k_se_bias_grad, dim3(cdiv(mcp_max + se_max, 256), ng), dim3(256), 0, s, d, a);
+    hipLaunchKernelGGL(k_se_bias_grad, dim3(cdiv(mcp_max + se_max, 64), ng), dim3(256), 0, s, d, a);
     return (int)hipGetLastError();
 }

@@ -43,10 +43,15 @@ class SearchState:
             self._mode = (weights, arch)
 
 
+FORCE_ALLREDUCE_AT_WORLD_1 = False     # bench.py sets this under torchrun so the RCCL path is exercised even on 1 GPU
+
+
 def allreduce_mean_(tensors, group=None):
     """Average a list of tensors across ranks with one flat all-reduce (no-op when not distributed)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or not tensors:
+    if not (dist.is_available() and dist.is_initialized()) or not tensors:
+        return
+    if dist.get_world_size(group) == 1 and not FORCE_ALLREDUCE_AT_WORLD_1:
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
