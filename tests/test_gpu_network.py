@@ -170,3 +170,24 @@ def test_stem_rejects_non_rgb_and_handles_odd_image_sizes(lut):
     ref = o.second_stem(F.relu(orc._bn(F.conv2d(x, o.first_stem.conv.weight, None, 2, 1))))
     got = m._stem(x.cuda())
     assert got.shape == ref.shape and torch.allclose(got.cpu(), ref, atol=1e-4, rtol=1e-3)
+
+
+def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
+    """The 'random' path on a second HIP stream must not change any result (kernels are deterministic)."""
+    from tfnas_amd import search
+    res = []
+    for overlap in (False, True):
+        _, m = _pair(lut)
+        st = search.SearchState(m)
+        ow, _ = search.make_optimizers(m)
+        g = torch.Generator().manual_seed(9)
+        for it in range(2):
+            x = torch.randn(4, 3, 224, 224, generator=g).cuda()
+            y = torch.randint(0, 100, (4,), generator=g).cuda()
+            ng = torch.empty(18, 8).exponential_(generator=g).cuda()
+            rp = [int(v) for v in torch.randint(0, 7, (18,), generator=g)]
+            search.w_step(st, x, y, ow, 5.0, noise_g=ng, rand_pos=rp, overlap_paths=overlap)
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in m.weight_parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

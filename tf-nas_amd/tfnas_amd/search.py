@@ -33,6 +33,13 @@ class SearchState:
         self.weights = model.weight_parameters()
         self.arch = model.arch_parameters()
         self._mode = None
+        self._side_stream = None
+
+    def side_stream(self, device):
+        """Second HIP stream for the 'random' path of the w-step (created once per device)."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream
 
     def require(self, weights, arch):
         if self._mode != (weights, arch):
@@ -80,13 +87,29 @@ class NoiseSource:
         return [self.rng.randrange(7) for _ in range(self.ncell)]
 
 
-def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, bi_sampling=True, group=None):
-    """Weight step: CE(gumbel path) [+ CE(random path)] -> backward -> (all-reduce) -> clip -> SGD."""
+def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, bi_sampling=True, group=None,
+           overlap_paths=True):
+    """Weight step: CE(gumbel path) [+ CE(random path)] -> backward -> (all-reduce) -> clip -> SGD.
+
+    The two sampled paths of bi-sampling are independent sub-graphs (different candidates, same input) whose
+    kernels are too small to fill 256 CUs at 128 images; with ``overlap_paths`` the 'random' path is enqueued on a
+    second HIP stream, so its forward -- and, because autograd replays every node on its forward stream, its
+    backward -- runs concurrently with the 'gumbel' path.  Same arithmetic, same results."""
     model = state.model
     state.require(True, False)
     logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g)
     loss = F.cross_entropy(logits_g, target)
-    if bi_sampling:
+    if bi_sampling and overlap_paths and x.is_cuda:
+        cur = torch.cuda.current_stream(x.device)
+        side = state.side_stream(x.device)
+        side.wait_stream(cur)                       # x, target and the weights are ready
+        with torch.cuda.stream(side):
+            logits_r, _ = model(x, True, 'random', rand_pos=rand_pos)
+            loss_r = F.cross_entropy(logits_r, target)
+        cur.wait_stream(side)
+        loss_r.record_stream(cur)
+        loss = loss + loss_r
+    elif bi_sampling:
         logits_r, _ = model(x, True, 'random', rand_pos=rand_pos)
         loss = loss + F.cross_entropy(logits_r, target)
     else:
