@@ -82,7 +82,7 @@ def mbconv_forward(x, p, k, stride, act, has_res, detail=None):
         y = y * gate
     pr = F.conv2d(y, p['proj'])
     if detail is not None:
-        detail['P'] = pr
+        detail['Z'], detail['P'] = y, pr
     y = _bn(pr)
     if has_res:
         y = y + x

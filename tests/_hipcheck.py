@@ -61,7 +61,7 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad):
     for i in idxs:
         det = {}
         ys.append(o.m_ops[i](xo, det))
-        for k in ('Eh', 'Dh'):
+        for k in ('Eh', 'Z'):
             det[k].retain_grad()
         details.append(det)
     out_o = sum(w_o[i] * y for i, y in zip(idxs, ys)) if soft else ys[0]
@@ -101,7 +101,7 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad):
         if 'gate' in det:
             res[tag + 'gate'] = err(gate[:, off:off + mc], det['gate'].flatten(1))
         res[tag + 'Pr'] = err(Pr[g], nhwc(det['P']))
-        res[tag + 'ddh'] = err(dZ[..., off:off + mc], nhwc(det['Dh'].grad))
+        res[tag + 'dZ'] = err(dZ[..., off:off + mc], nhwc(det['Z'].grad))
         res[tag + 'dEh'] = err(dEh[..., off:off + mc], nhwc(det['Eh'].grad))
     res['out'] = err(out_m, out_o)
     res['dx'] = err(xm.grad, xo.grad)

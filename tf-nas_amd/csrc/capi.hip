@@ -158,9 +158,9 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
     if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, s));
-    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));     // dZ <- d dhat ; BN2 backward sums
-    TRY(launch_dw_bwd_data(d, dZ, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
-    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, D, stats2, red2, E, stats1, part, s));
+    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));     // BN2 backward sums
+    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
+    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     if (d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));

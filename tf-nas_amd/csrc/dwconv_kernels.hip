@@ -214,15 +214,23 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
 }
 
 // ---------------------------------------------------------------------------- BN2-backward operand
-// ddh = d loss / d dhat (stored in place of dZ by k_bn2_bwd);  dd = rstd2*(ddh - R1/Po - dhat*R2/Po)
-// cst2[c] = (mean2, rstd2, R1/Po, R2/Po)
-__device__ __forceinline__ f32x4 bn2_dd(const f32x4* cst2, int cl, f32x4 ddh, f32x4 dv) {
+// From dZ (gradient w.r.t. the gated activation that feeds the project conv) to dd (gradient w.r.t. the raw depthwise
+// output D), i.e. the backward of  D -> BN2 -> act -> (* gate, SE pool path):
+//   dhat = (D - mean2) * rstd2 ; da = dZ*gate + dpooled/HW  (SE groups; else dZ) ; ddh = da * act'(dhat)
+//   dd   = rstd2 * (ddh - R1/Po - dhat * R2/Po)            R1 = sum ddh, R2 = sum ddh*dhat  (k_bn2_bwd)
+// cst2[c] = (mean2, rstd2, R1/Po, R2/Po).  ddh is recomputed here instead of being written back by k_bn2_bwd
+// (saves one write + nothing extra to read: dZ replaces ddh).
+template <int ACT>
+__device__ __forceinline__ f32x4 bn2_dd(const f32x4* cst2, int cl, f32x4 dz, f32x4 dv, bool has_se, f32x4 gate4,
+                                        f32x4 dpool4) {
     f32x4 r;
+    if (has_se) dz = dz * gate4 + dpool4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f32x4 t = cst2[cl + j];
         const float dh = (dv[j] - t.x) * t.y;
-        r[j] = t.y * (ddh[j] - t.z - dh * t.w);
+        const float ddh = dz[j] * act_d<ACT>(dh);
+        r[j] = t.y * (ddh - t.z - dh * t.w);
     }
     return r;
 }
@@ -247,7 +255,8 @@ __device__ __forceinline__ void fill_cst2(f32x4* cst2, const TfnasCellDesc& d, i
 // dA1[n][hi][wi][c] = sum_{ky,kx} dd[n][(hi+p-ky)/S][(wi+p-kx)/S][c] * w[c][ky][kx]   (only exact divisions)
 // epilogue: deh = dA1 * act'(ehat) -> dEh, and the BN1-backward sums (T1 = sum deh, T2 = sum deh*ehat)
 template <int K, int S, int ACT>
-__global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const float* __restrict__ ddh,
+__global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const float* __restrict__ dZ,
+                                                        const float* __restrict__ gate, const float* __restrict__ dpooled,
                                                         const float* __restrict__ D, const double* __restrict__ stats2,
                                                         const double* __restrict__ red2, const float* __restrict__ E,
                                                         const double* __restrict__ stats1, float* __restrict__ dEh,
@@ -275,19 +284,28 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
     stage_weights(wts, d.g[g].w_dw, K * K, CC, c0, mc);
 
     const int nsw = TIW >> 2, nstrips = TIH * nsw;
+    const bool has_se = d.g[g].se > 0;
+    const float inv_hw = 1.f / (float)(Ho * Wo);
     f32x4 t1 = zero4(), t2 = zero4();
     for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int hi0 = th * TIH, wi0 = tw * TIW;
         const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
         __syncthreads();
-        load_tile2(dd_tile, OH, OW, CC, gm.cq_shift, ddh, D,
+        // this thread always stages the same channel quad (256 % CQ == 0): its SE gate / pool-path terms of image n
+        const int mycq = tid & (CQ - 1);
+        f32x4 g4 = zero4(), dp4 = zero4();
+        if (has_se && c0 + 4 * mycq < mcp) {
+            g4 = ld4(gate + (size_t)n * M + off + c0 + 4 * mycq);
+            dp4 = ld4(dpooled + (size_t)n * M + off + c0 + 4 * mycq) * splat4(inv_hw);
+        }
+        load_tile2(dd_tile, OH, OW, CC, gm.cq_shift, dZ, D,
                    [&](int r, int c, int cq, size_t& a) {
                        const int ho = oh0 + r, wo = ow0 + c;
                        a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
                        return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
                    },
-                   [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd(cst2, 4 * cq, v, dv); });
+                   [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd<ACT>(cst2, 4 * cq, v, dv, has_se, g4, dp4); });
         __syncthreads();
 
         for (int item = tid; item < nstrips * CQ; item += 256) {
@@ -295,6 +313,14 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
             const int ih = st / nsw, iw0 = (st - ih * nsw) * 4;
             const int hi = hi0 + ih;
             f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+            // issue the epilogue's E loads now so that their latency hides under the tap loop
+            f32x4 ev[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wi = wi0 + iw0 + j;
+                const bool okj = hi < H && wi < W && c0 + 4 * cq < mcp;
+                ev[j] = okj ? ld4(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq) : zero4();
+            }
             if (S == 1) {
                 // column of output (wi + PAD - kx) relative to ow0 = wi0 + PAD - (K-1):  iw0 + j - kx + K - 1
 #pragma unroll 1
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                     const int wi = wi0 + iw0 + j;
                     if (wi < W) {
                         const size_t a = ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq;
-                        const f32x4 e = ld4(E + a);
+                        const f32x4 e = ev[j];
                         f32x4 deh;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -361,7 +387,8 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
 // part[bx][poff_g + c*K*K + ky*K + kx] = sum over this workgroup's tiles of dd[n][ho][wo][c] * a1[n][ho*S+ky-p][wo*S+kx-p][c]
 // (a1 = act(BN1(E))); k_reduce_rows sums the workgroups into g_dw
 template <int K, int S, int ACT>
-__global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const float* __restrict__ ddh,
+__global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const float* __restrict__ dZ,
+                                                     const float* __restrict__ gate, const float* __restrict__ dpooled,
                                                      const float* __restrict__ D, const double* __restrict__ stats2,
                                                      const double* __restrict__ red2, const float* __restrict__ E,
                                                      const double* __restrict__ stats1, float* __restrict__ part,
@@ -390,6 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
 
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
+    const bool has_se = d.g[g].se > 0;
+    const float inv_hw = 1.f / (float)(Ho * Wo);
     f32x4 wacc[K * K];
 #pragma unroll
     for (int u = 0; u < K * K; ++u) wacc[u] = zero4();
@@ -397,6 +426,12 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int ho0 = th * TH, wo0 = tw * TW;
         const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
+        const int mycq = tid & (CQ - 1);
+        f32x4 g4 = zero4(), dp4 = zero4();
+        if (has_se && c0 + 4 * mycq < mcp) {
+            g4 = ld4(gate + (size_t)n * M + off + c0 + 4 * mycq);
+            dp4 = ld4(dpooled + (size_t)n * M + off + c0 + 4 * mycq) * splat4(inv_hw);
+        }
         __syncthreads();
         load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
                   [&](int r, int c, int cq, size_t& a) {
@@ -424,11 +459,11 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
                 const int wo = wo0 + ow0 + j;
                 ok[j] = ho < Ho && wo < Wo && c0 + 4 * cq < mcp;
                 const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-                dd[j] = ok[j] ? ld4(ddh + a) : zero4();
+                dd[j] = ok[j] ? ld4(dZ + a) : zero4();
                 dv[j] = ok[j] ? ld4(D + a) : zero4();
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dd[j] = ok[j] ? bn2_dd(cst2, 4 * cq, dd[j], dv[j]) : zero4();
+            for (int j = 0; j < 4; ++j) dd[j] = ok[j] ? bn2_dd<ACT>(cst2, 4 * cq, dd[j], dv[j], has_se, g4, dp4) : zero4();
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 const float* rowp = in_tile + ((oh * S + ky) * IW + ow0 * S) * CC + 4 * cq;
@@ -554,7 +589,8 @@ int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, 
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
-int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
+                       const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
                        float* part, hipStream_t s) {
     ProfScope _prof(TK_DW_BWD_DATA, s);
@@ -568,14 +604,15 @@ int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D,
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
         DW_DISPATCH(kk, d.stride, d.act, {
-            hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT>), grid, dim3(256), shm, s, d, ddh, D, stats2, red2, E,
+            hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E,
                                stats1, dEh, part, gm);
         })
     }
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 
-int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
+                    const double* stats2,
                     const double* red2, const float* E, const double* stats1, float* part, hipStream_t s) {
     ProfScope _prof(TK_DW_WGRAD, s);
     size_t out_size = 0;
@@ -591,7 +628,7 @@ int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, co
         const size_t shm = (size_t)(tile + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
         DW_DISPATCH(kk, d.stride, d.act, {
-            hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT>), grid, dim3(256), shm, s, d, ddh, D, stats2, red2, E, stats1,
+            hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E, stats1,
                                part, out_size, gm);
         })
     }

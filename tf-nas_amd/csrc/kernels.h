@@ -22,10 +22,12 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
 // dwconv_kernels.hip
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
                   float* part, hipStream_t s);
-int launch_dw_bwd_data(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
+                       const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
                        float* part, hipStream_t s);
-int launch_dw_wgrad(const TfnasCellDesc& d, const float* ddh, const float* D, const double* stats2,
+int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
+                    const double* stats2,
                     const double* red2, const float* E, const double* stats1, float* part, hipStream_t s);
 
 // pointwise_kernels.hip (SE squeeze, BN2 backward statistics, mixing epilogue, BN constant tables)
@@ -43,7 +45,7 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
                      float* dgl, float* dhpre, float* dpooled, hipStream_t s);
 int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* dhpre,
                     const float* hpre, const float* pooled, hipStream_t s);
-int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
+int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, const float* gate,
                    const float* dpooled, double* red2, float* part, hipStream_t s);
 int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats1, float* pooled, hipStream_t s);
 int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1, const float* dpooled, float* dEh,

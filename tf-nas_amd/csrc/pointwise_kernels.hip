@@ -195,9 +195,10 @@ __global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const
 }
 
 // ============================================================================ BN2 backward, pass 1
-// in place: dZ <- ddh = (dZ*gate + dpooled/HW) * act'(dhat) ;  red2[c] = (sum ddh, sum ddh*dhat)
+// ddh = (dZ*gate + dpooled/HW) * act'(dhat) ;  red2[c] = (sum ddh, sum ddh*dhat)   (sums only: the consumers
+// k_dw_bwd_data / k_dw_wgrad recompute ddh from dZ in their tile loaders, so nothing is written back here)
 template <int ACT>
-__global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, float* __restrict__ dZ, const float* __restrict__ D,
+__global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, const float* __restrict__ dZ, const float* __restrict__ D,
                                                  const double* __restrict__ stats2, const float* __restrict__ gate,
                                                  const float* __restrict__ dpooled, float* __restrict__ part,
                                                  int rows_per_block) {
@@ -246,7 +247,6 @@ __global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, float* __restr
                         r1[j] += ddh[j];
                         r2[j] += ddh[j] * dh;
                     }
-                    st4(dZ + (size_t)p * M + off + ch, ddh);
                 }
             }
         }
@@ -451,7 +451,7 @@ int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resd
     return (int)hipGetLastError();
 }
 
-int launch_bn2_bwd(const TfnasCellDesc& d, float* dZ, const float* D, const double* stats2, const float* gate,
+int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, const float* gate,
                    const float* dpooled, double* red2, float* part, hipStream_t s) {
     ProfScope _prof(TK_BN2_BWD, s);
     const int Po = d.N * d.Ho * d.Wo;
