@@ -137,7 +137,8 @@ int tfnas_mixedop_fwd(const TfnasCellDesc *d, const float *x, const float *wmix,
 
 /* MixedOP backward (what autograd does for the graph above).  Produces dx [N*H*W][ic], dwmix[G]
  * (d loss / d wmix[g]; may be NULL in sampled mode) and, when d->need_wgrad, the g_* weight gradients
- * (overwritten, not accumulated).  dZ/dEh/bsmall/red/part are scratch. */
+ * (overwritten, not accumulated).  dZ/dEh/bsmall/red/part are scratch.  dx may be NULL when the input needs
+ * no gradient: with need_wgrad == 0 only dwmix is produced (everything else is skipped). */
 int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
                       const float *E, const float *D, const float *Pr, const float *fsmall,
                       const double *stats, const float *dout,

@@ -108,3 +108,23 @@ def test_hip_cell_matches_committed_reference_vectors(name):
         for k, p in m.m_ops[idx].named_parameters():
             want = fx['samp%d_g.%s' % (idx, k)]
             assert np.allclose(p.grad.cpu().numpy(), want, atol=1e-4 + 1e-4 * abs(want).max(), rtol=1e-3), k
+
+
+def test_backward_without_input_grad_only_produces_dwmix():
+    """alpha-step, first cell: input and weights need no gradient -> only d wmix is computed (and it is right)."""
+    from tfnas_amd.functions import MixedOpFn
+    import tfnas_oracle as orc
+    o, m, x, r, e = _inputs(CONFIGS[1])
+    w_o = orc.gumbel_softmax(o.log_alphas, o.T, e)
+    w_o.retain_grad()
+    out_o = sum(w_o[i] * op(x) for i, op in enumerate(o.m_ops))
+    (out_o * r).sum().backward()
+    plan = m._plan(tuple(range(8)))
+    ps = plan.params()
+    for p in ps:
+        p.requires_grad_(False)
+    w_m = w_o.detach().cuda().requires_grad_(True)
+    xm = x.cuda().contiguous(memory_format=torch.channels_last)          # requires_grad = False
+    out_m = MixedOpFn.apply(plan, xm, w_m, *ps)
+    (out_m * r.cuda()).sum().backward()
+    assert torch.allclose(w_m.grad.cpu(), w_o.grad, atol=1e-3 + 1e-3 * float(w_o.grad.abs().max()))

@@ -125,7 +125,6 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
-    if (!dx && d.mode != TFNAS_MODE_STEM) return TFNAS_ENULL;     // the stem's input is the image: no dx
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
@@ -153,6 +152,9 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     }
     TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, x, red3, part, s));           // BN3 backward sums (+ d wmix)
     if (dwmix) TRY(launch_mix_dw(d, red3, red + ws.off_resdot, dwmix, s));
+    // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
+    // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
+    if (!dx && !d.need_wgrad) return 0;
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
     if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part, s));
     TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
@@ -162,7 +164,7 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
-    if (d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
+    if (dx && d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }

@@ -120,8 +120,9 @@ def _cell_backward(ctx, dout, want_dx):
     grads = [torch.empty_like(p) for p in params] if need_w else None
     plan.bind(d, params, grads)
     douth = _nhwc(dout)
-    dZ = torch.empty(ws.dZ, device=dev, dtype=torch.float32)
-    dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
+    light = not want_dx and not need_w          # only d wmix is wanted: the C side returns after the BN3 sums
+    dZ = torch.empty(4 if light else ws.dZ, device=dev, dtype=torch.float32)
+    dEh = torch.empty(4 if light else ws.dEh, device=dev, dtype=torch.float32)
     bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
     part = torch.empty(ws.part, device=dev, dtype=torch.float32)
@@ -153,7 +154,7 @@ class MixedOpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        return _cell_backward(ctx, dout, True)
+        return _cell_backward(ctx, dout, ctx.needs_input_grad[1])
 
 
 class StemFn(torch.autograd.Function):
