@@ -43,19 +43,24 @@ def cell_table(B):
 
 
 def family_algorithmic(fam, B):
-    """Algorithmic (flops, bytes) summed over the launches one iteration pair makes of kernel family `fam`,
-    plus the launch count.  alpha-step: all 8 candidates of the 18 cells; w-step: 2 paths x 18 cells x 1
-    candidate x 2 w-steps (expected value over uniform candidate choice).  fp32 = 4 B/element.
-    Only families that can dominate are modelled; others return None."""
+    """Algorithmic (flops, bytes) summed over the KERNEL launches one iteration pair makes of kernel family `fam`,
+    plus that launch count.  alpha-step: all 8 candidates of the 18 cells (backward kernels skip the first cell,
+    whose input needs no gradient); w-step: 2 paths x 18 cells x 1 candidate x 2 w-steps (expected value over
+    uniform candidate choice).  Depthwise families launch one kernel per kernel size present (2 in the soft
+    mode).  fp32 = 4 B/element.  Only families that can dominate are modelled; others return None."""
     from tfnas_amd import geometry as g
     fl = by = 0.0
     n = 0
-    for name, N, H, W, ic, oc, s, mids in cell_table(B):
+    backward = fam in ('k_project_dgrad', 'k_expand_dgrad', 'k_dw_bwd_data', 'k_bn2_bwd')
+    for ci, (name, N, H, W, ic, oc, s, mids) in enumerate(cell_table(B)):
         P, Po = N * H * W, N * ((H - 1) // s + 1) * ((W - 1) // s + 1)
         Msoft = sum(mids)
         Mavg = Msoft / 8.0
         for M, launches in ((Msoft, 1), (Mavg, 4)):          # soft launch once, sampled launch 4x per pair
             G = 8 if launches == 1 else 1
+            if launches == 1 and backward and ci == 0:
+                continue                                       # pruned: first cell of the alpha-step
+            kernels = launches * (2 if (fam.startswith('k_dw_') and launches == 1) else 1)
             if fam == 'k_expand_fwd':
                 f, b = 2.0 * P * ic * M, 4.0 * (P * ic + P * M + M * ic)
             elif fam == 'k_project_fwd':
@@ -85,7 +90,7 @@ def family_algorithmic(fam, B):
                 return None
             fl += f * launches
             by += b * launches
-            n += launches
+            n += kernels
     return fl, by, n
 
 

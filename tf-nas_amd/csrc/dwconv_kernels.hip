@@ -572,7 +572,6 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
 
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
                   float* part, hipStream_t s) {
-    ProfScope _prof(TK_DW_FWD, s);
     const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
@@ -582,6 +581,7 @@ int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, 
         const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
+        ProfScope _prof(TK_DW_FWD, s);
         DW_DISPATCH(kk, d.stride, d.act, {
             hipLaunchKernelGGL((k_dw_fwd<K, S, ACT>), grid, dim3(256), shm, s, d, E, stats1, D, part, gm);
         })
@@ -593,7 +593,6 @@ int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gat
                        const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
                        float* part, hipStream_t s) {
-    ProfScope _prof(TK_DW_BWD_DATA, s);
     const int gx = dw_common_gx(d, d.H, d.W, false, 4096, 2 * (size_t)d.M);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
@@ -603,6 +602,7 @@ int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gat
         const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
+        ProfScope _prof(TK_DW_BWD_DATA, s);
         DW_DISPATCH(kk, d.stride, d.act, {
             hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E,
                                stats1, dEh, part, gm);
@@ -614,7 +614,6 @@ int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gat
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
                     const double* stats2,
                     const double* red2, const float* E, const double* stats1, float* part, hipStream_t s) {
-    ProfScope _prof(TK_DW_WGRAD, s);
     size_t out_size = 0;
     for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.g[g].k * d.g[g].k;
     const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 2048, out_size);
@@ -627,6 +626,7 @@ int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, 
         if (tile < 4 * kk * kk * gm.CC) tile = 4 * kk * kk * gm.CC;
         const size_t shm = (size_t)(tile + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
+        ProfScope _prof(TK_DW_WGRAD, s);
         DW_DISPATCH(kk, d.stride, d.act, {
             hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E, stats1,
                                part, out_size, gm);

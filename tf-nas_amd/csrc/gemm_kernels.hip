@@ -489,6 +489,7 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
         hipLaunchKernelGGL((k_expand_fwd<NT, true>), grid, dim3(256), 0, s, d, x, E, part);
     else
         hipLaunchKernelGGL((k_expand_fwd<NT, false>), grid, dim3(256), 0, s, d, x, E, part);
+    _prof.stop();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
@@ -505,6 +506,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part);
     }))
+    _prof.stop();
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
 }
 
@@ -549,6 +551,7 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
         hipLaunchKernelGGL((k_project_wgrad<NT, ACT>), grid, dim3(256), shm, s, d, dout, Pr, D, gate, stats2,
                            stats3, red3, wmix, rps, ntiles, part, out_size);
     }))
+    _prof.stop();
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {
         const int n = d.g[g].mc * d.oc;
@@ -582,7 +585,9 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E
     DISPATCH_NT(nt, {
         hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, dout, wmix, dx, dxp, nsplit);
     })
+    _prof.stop();
     if (nsplit > 1) {
+        ProfScope _p2(TK_SMALL, s);
         const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
         size_t blocks = cdiv64(n4, 256 * 2);
         if (blocks > 2048) blocks = 2048;
@@ -609,6 +614,7 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
         else
             hipLaunchKernelGGL((k_expand_wgrad<NT, false>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
     })
+    _prof.stop();
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {
         const int n = d.g[g].mc * d.ic;

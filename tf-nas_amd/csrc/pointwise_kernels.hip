@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
 
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s) {
+    ProfScope _prof(TK_REDUCE_ROWS, s);
     hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(ncols, 8)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
     return (int)hipGetLastError();
 }
@@ -442,6 +443,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
     const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
     const int gx = cdiv(Po, rpb);
     hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
+    _prof.stop();
     return launch_reduce_rows(part, gx, ncols, (size_t)ncols, red3, nullptr, s);
 }
 
@@ -466,6 +468,7 @@ int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, cons
     ACT_DISPATCH(d.act, {
         hipLaunchKernelGGL((k_bn2_bwd<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, gate, dpooled, part, rpb);
     })
+    _prof.stop();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, red2, nullptr, s);
 }
 
@@ -482,6 +485,7 @@ int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1
     if ((size_t)d.N * 2 * d.M > TFNAS_PART_FLOATS) return TFNAS_ERANGE;
     dim3 grid(d.N, cdiv(d.g[0].mcp, 64));
     ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_head_bwd<ACT>), grid, dim3(256), 0, s, d, E, stats1, dpooled, dEh, part); })
+    _prof.stop();
     return launch_reduce_rows(part, d.N, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 

@@ -6,7 +6,7 @@
 enum TfnasKernelId {
     TK_EXPAND_FWD = 0, TK_DW_FWD, TK_SE_POOL, TK_SE_FC_FWD, TK_PROJECT_FWD, TK_MIX_FWD,
     TK_MIX_BWD_STATS, TK_PROJECT_DGRAD, TK_PROJECT_WGRAD, TK_SE_BWD_REDUCE, TK_SE_FC_BWD, TK_SE_WGRAD,
-    TK_BN2_BWD, TK_DW_BWD_DATA, TK_DW_WGRAD, TK_EXPAND_DGRAD, TK_EXPAND_WGRAD, TK_SMALL, TK_COUNT
+    TK_BN2_BWD, TK_DW_BWD_DATA, TK_DW_WGRAD, TK_EXPAND_DGRAD, TK_EXPAND_WGRAD, TK_SMALL, TK_REDUCE_ROWS, TK_COUNT
 };
 
 struct ProfScope {
@@ -15,5 +15,6 @@ struct ProfScope {
     hipEvent_t e0;
     bool on;
     ProfScope(int id, hipStream_t s);
-    ~ProfScope();
+    void stop();          // record the end event now (idempotent); the destructor calls it
+    ~ProfScope() { stop(); }
 };

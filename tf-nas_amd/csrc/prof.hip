@@ -10,15 +10,17 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_ev[TK_COUNT];
 static const char* kNames[TK_COUNT] = {
     "k_expand_fwd", "k_dw_fwd", "k_se_pool<fwd>", "k_se_fc_fwd", "k_project_fwd", "k_mix_fwd",
     "k_mix_bwd_stats", "k_project_dgrad", "k_project_wgrad", "k_se_pool<bwd>", "k_se_fc_bwd", "k_se_wgrad",
-    "k_bn2_bwd", "k_dw_bwd_data", "k_dw_wgrad", "k_expand_dgrad", "k_expand_wgrad", "small(arch/sink/consts)"};
+    "k_bn2_bwd", "k_dw_bwd_data", "k_dw_wgrad", "k_expand_dgrad", "k_expand_wgrad", "small(arch/sink/consts)",
+    "k_reduce_rows"};
 
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), e0(nullptr), on(false) {
     if (g_mask & (1u << id)) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventRecord(e0, s) == hipSuccess) on = true;
     }
 }
-ProfScope::~ProfScope() {
+void ProfScope::stop() {
     if (!on) return;
+    on = false;
     hipEvent_t e1;
     if (hipEventCreate(&e1) != hipSuccess) return;
     hipEventRecord(e1, s);
