@@ -191,3 +191,69 @@ def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
         res.append([p.detach().clone() for p in m.weight_parameters()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def _pair_with_widths(lut, mc, seed=2, T=5.0):
+    from tfnas_amd import Network
+    torch.manual_seed(seed)
+    o = orc.Network(100, mc, lut)
+    torch.manual_seed(seed)
+    m = Network(100, mc, lut)
+    o.set_temperature(T); m.set_temperature(T)
+    return o, m.cuda()
+
+
+@pytest.mark.parametrize('widths', ['e2_e4', 'e4_e8', 'ragged_target15', 'ragged_target10'])
+def test_width_sweep_matches_oracle(lut, widths):
+    """BASELINE configs[3]: expand ratios across the reachable range + ragged widths produced by elasticity scaling
+    (fit_mc_num_by_latency), latency lookup executed in the soft forward."""
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g
+    from tfnas_amd.elasticity import fit_mc_num_by_latency
+    from tfnas_amd.latency import get_lookup_latency
+    if widths == 'e2_e4':
+        mc = g.uniform_mc_num_dddict(2, 4)
+    elif widths == 'e4_e8':
+        mc = g.uniform_mc_num_dddict(4, 8)
+    else:
+        base = g.initial_mc_num_dddict()
+        mcmax = g.get_mc_num_dddict(g.make_mc_mask_dddict(), is_max=True)
+        keys = g.make_lat_lookup_key_dddict()
+        target = 15.0 if widths.endswith('15') else 10.0
+        mc = base
+        for op in (1, 7, 4):                                   # scale three different candidates -> many ragged widths
+            arch = OrderedDict((st, OrderedDict((b, op) for b in base[st])) for st in base)
+            lat = get_lookup_latency(arch, mc, keys, lut)
+            mc, _ = fit_mc_num_by_latency(arch, mc, mcmax, keys, lut, target, list(base.keys()), -1 if lat > target else 1)
+        if target == 15.0:          # (target 10 clips to the floor widths max//2, which are multiples of 4)
+            assert any(v % 4 for st in mc.values() for b in st.values() for v in b.values())
+    o, m = _pair_with_widths(lut, mc)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 224, 224, generator=gen)
+    noise = torch.empty(18, 8).exponential_(generator=gen)
+    with torch.no_grad():
+        lo, lato = o(x, False, exp_noise=noise)
+        lm, latm = m(x.cuda(), False, exp_noise=noise.cuda())
+        so, _ = o(x, True, 'gumbel', exp_noise=noise)
+        sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    assert abs(float(lato) - float(latm)) < 1e-3
+    assert torch.allclose(lm.cpu(), lo, atol=1e-3, rtol=1e-3), float((lm.cpu() - lo).abs().max())
+    assert torch.allclose(sm.cpu(), so, atol=1e-3, rtol=1e-3)
+
+
+def test_warmup_step_without_arch_matches_oracle(lut):
+    """train_wo_arch (train_search.py:329-342): single gumbel path, switches reset, SGD step."""
+    from tfnas_amd import search
+    o, m = _pair(lut)
+    oo, mo = orc.make_optimizers(o), search.make_optimizers(m)
+    st = search.SearchState(m)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (4,), generator=g)
+    ng = torch.empty(18, 8).exponential_(generator=g)
+    lo_, _, gi, _ = orc.w_step(o, x, y, oo[0], 5.0, noise_g=ng, bi_sampling=False)
+    lm_, _ = search.w_step(st, x.cuda(), y.cuda(), mo[0], 5.0, noise_g=ng.cuda(), bi_sampling=False)
+    assert abs(float(lo_) - float(lm_)) < 1e-3
+    assert all(all(c.switches) for c in m.cells())
+    for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
+        assert torch.allclose(b.detach().cpu(), a.detach(), atol=1e-4, rtol=1e-3), k

@@ -26,6 +26,15 @@ struct DwGeom {
 
 __device__ __forceinline__ int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
+// XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 and every XCD has a private L2; spatially
+// adjacent tiles share halo pixels, so they should be in flight on the SAME XCD.  With gridDim.x a multiple of 8 the
+// workgroups of XCD x take the contiguous tile range [x*gx/8, (x+1)*gx/8) of every grid-stride round (pure speed
+// heuristic: any placement gives the same results).
+__device__ __forceinline__ int xcd_first_tile() {
+    const int gx = gridDim.x, bx = blockIdx.x;
+    return (gx & 7) ? bx : (bx & 7) * (gx >> 3) + (bx >> 3);
+}
+
 // locate (group, first channel) of channel-chunk `cy` among the groups whose kernel size is K
 template <int K>
 __device__ __forceinline__ bool dw_locate(const TfnasCellDesc& d, int cy, int CC, int& g, int& c0) {
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
     f32x4 ssum = zero4(), ssq = zero4();
-    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+    for (int t = xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int ho0 = th * TH, wo0 = tw * TW;
         const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
     const bool has_se = d.g[g].se > 0;
     const float inv_hw = 1.f / (float)(Ho * Wo);
     f32x4 t1 = zero4(), t2 = zero4();
-    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+    for (int t = xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int hi0 = th * TIH, wi0 = tw * TIW;
         const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
     f32x4 wacc[K * K];
 #pragma unroll
     for (int u = 0; u < K * K; ++u) wacc[u] = zero4();
-    for (int t = blockIdx.x; t < gm.ntiles; t += gridDim.x) {
+    for (int t = xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int ho0 = th * TH, wo0 = tw * TW;
         const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
@@ -567,6 +576,7 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
     const size_t cap = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
     if ((size_t)gx > cap) gx = (int)cap;
     if (gx > 1024) gx = 1024;                      // partial rows to reduce afterwards
+    if (gx >= 8) gx &= ~7;                         // multiple of 8 for the XCD-aware tile order
     return gx < 1 ? 1 : gx;
 }
 
