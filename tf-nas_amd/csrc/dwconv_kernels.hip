@@ -580,8 +580,8 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
     return gx < 1 ? 1 : gx;
 }
 
-int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
-                  float* part, hipStream_t s) {
+static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
+                              float* part, hipStream_t s) {
     const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
@@ -651,3 +651,5 @@ int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, 
     }
     return (int)hipGetLastError();
 }
+
+#include "dw_stream.inc"
