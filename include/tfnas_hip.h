@@ -108,7 +108,10 @@ typedef struct TfnasCellWs {
     uint64_t red;      /* doubles red3[G*oc][2] | resdot[oc] | red2[M][2] | red1[M][2]      */
     uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = per-channel <dout, x> of residual cells */
     uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd); reductions are done by a
-                          second tiny kernel instead of device-scope atomics -> deterministic results          */
+                          second tiny kernel instead of device-scope atomics -> deterministic results.
+                          Doubled when d.need_wgrad is set: tfnas_mixedop_bwd runs the weight-gradient kernels on
+                          a library-owned side stream (forked from / joined to `stream` inside the call) and gives
+                          them the second half.                                                              */
     uint64_t dx;       /* floats  [N*H*W][ic]                                               */
     uint64_t dxp;      /* floats  split-K partial tiles of the expand dgrad (may be tiny); pass NULL to disable */
 } TfnasCellWs;

@@ -4,7 +4,65 @@
 #include "tfnas_dev.h"
 #include "kernels.h"
 
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient side stream.  The weight-gradient kernels of a cell are leaves of the backward dependency chain
+// (nothing downstream in the same call consumes them), and like most kernels of the sampled w-step they are
+// latency- rather than throughput-bound, so they are enqueued on a second HIP stream owned by the library
+// (one per caller stream and device) and overlap with the data-gradient chain of the same cell: fork events
+// after the producers of their operands, one join before tfnas_mixedop_bwd returns control to the caller's stream
+// (so from the caller's point of view everything is still ordered on `stream`).  They use the second half of `part`.
+// TFNAS_WGRAD_STREAM=0 disables the side stream (everything on the caller's stream, identical results).
+struct SideCtx {
+    int device;
+    hipStream_t main, side;
+    hipEvent_t fork[4], join;
+};
+static std::mutex g_side_mu;
+static std::vector<SideCtx*> g_side;
+
+static bool side_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TFNAS_WGRAD_STREAM");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+static SideCtx* side_for(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (SideCtx* c : g_side)
+        if (c->main == s && c->device == dev) return c;
+    SideCtx* c = new SideCtx();
+    c->device = dev;
+    c->main = s;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    bool ok = hipEventCreateWithFlags(&c->join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete c; return nullptr; }
+    g_side.push_back(c);
+    return c;
+}
+// make `side` wait for everything enqueued on `main` so far; returns the stream to launch on
+static hipStream_t side_fork(SideCtx* c, int k, hipStream_t main) {
+    if (!c) return main;
+    if (hipEventRecord(c->fork[k], main) != hipSuccess || hipStreamWaitEvent(c->side, c->fork[k], 0) != hipSuccess)
+        return main;
+    return c->side;
+}
+static int side_join(SideCtx* c, hipStream_t main) {
+    if (!c) return 0;
+    hipError_t e = hipEventRecord(c->join, c->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, c->join, 0);
+    return (int)e;
+}
 
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
@@ -79,7 +137,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_red2 = 2 * G * oc + oc;
     ws->off_red1 = ws->off_red2 + 2 * M;
     ws->red = ws->off_red1 + 2 * M;
-    ws->part = TFNAS_PART_FLOATS;
+    ws->part = (d->need_wgrad ? 2 : 1) * (uint64_t)TFNAS_PART_FLOATS;   // second half: weight-gradient side stream
     ws->dx = P * d->ic;
     {
         const int ns = d->mode == TFNAS_MODE_STEM ? 1 : expand_dgrad_splits(*d);
@@ -155,18 +213,21 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
     // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
     if (!dx && !d.need_wgrad) return 0;
+    // weight gradients: on the library's side stream (see SideCtx), scratch = second half of `part`
+    SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
+    float* part_w = part + TFNAS_PART_FLOATS;
+    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part_w, side_fork(sc, 0, s)));
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
-    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part, s));
     TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
-    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, s));
+    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, side_fork(sc, 1, s)));
     TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));     // BN2 backward sums
+    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, side_fork(sc, 2, s)));
     TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
-    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part, s));
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
     if (dx && d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
-    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
-    return 0;
+    return side_join(sc, s);
 }
 
 extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E, double* stats, float* part,

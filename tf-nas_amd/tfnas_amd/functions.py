@@ -125,7 +125,8 @@ def _cell_backward(ctx, dout, want_dx):
     dEh = torch.empty(4 if light else ws.dEh, device=dev, dtype=torch.float32)
     bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
-    part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+    # with weight gradients the library wants twice the scratch (second half: its weight-gradient side stream)
+    part = torch.empty(ws.part * (2 if need_w else 1), device=dev, dtype=torch.float32)
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
