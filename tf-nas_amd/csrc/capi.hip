@@ -218,10 +218,13 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     float* part_w = part + TFNAS_PART_FLOATS;
     if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part_w, side_fork(sc, 0, s)));
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
-    TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
+    const bool fused2 = bn2_fused_fits(d);
+    if (fused2) TRY(launch_bn2_pool(d, dZ, D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
+    else TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
     if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, side_fork(sc, 1, s)));
-    TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));     // BN2 backward sums
+    if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
+    else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, side_fork(sc, 2, s)));
     TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));

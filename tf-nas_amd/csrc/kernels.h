@@ -45,6 +45,11 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
                      float* dgl, float* dhpre, float* dpooled, hipStream_t s);
 int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* dhpre,
                     const float* hpre, const float* pooled, hipStream_t s);
+bool bn2_fused_fits(const TfnasCellDesc& d);
+int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, float* dgate,
+                    float* pp, hipStream_t s);
+int launch_bn2_finish(const TfnasCellDesc& d, const float* pp, const float* gate, const float* dpooled, double* red2,
+                      hipStream_t s);
 int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, const float* gate,
                    const float* dpooled, double* red2, float* part, hipStream_t s);
 int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats1, float* pooled, hipStream_t s);

@@ -194,6 +194,129 @@ __global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const
     }
 }
 
+// ============================================================================ BN2 backward sums, fused with the SE pool backward
+// One pass over (dZ, D) per image and channel chunk produces everything the BN2 backward needs:
+//   ddh = (dZ*gate + dpooled/HW) * act'(dhat)   is linear in the per-image scalars gate[n][c], dpooled[n][c], so
+//   sum_p ddh        = sum_n ( gate*A1 + dpooled/HW*A2 ),   A1 = sum_hw dZ*act'(dhat),       A2 = sum_hw act'(dhat)
+//   sum_p ddh*dhat   = sum_n ( gate*B1 + dpooled/HW*B2 ),   B1 = sum_hw dZ*act'(dhat)*dhat,  B2 = sum_hw act'(dhat)*dhat
+// and the same pass yields dgate[n][c] = sum_hw dZ*act(dhat) (what k_se_pool<MODE 1> computed), which the SE FC backward
+// needs BEFORE dpooled exists.  k_bn2_finish then folds the [N][M] tables into red2 once dpooled is known.  This replaces
+// the separate k_se_pool<bwd> and k_bn2_bwd passes (two reads of dZ and D) and one k_reduce_rows launch.
+// pp = [4][N][M] floats (A1 | B1 | A2 | B2; the last two only for SE groups).
+template <int ACT>
+__global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* __restrict__ dZ, const float* __restrict__ D,
+                                                  const double* __restrict__ stats2, float* __restrict__ dgate,
+                                                  float* __restrict__ pp) {
+    __shared__ f32x4 buf[256];
+    int g, c0;
+    if (!chunk_locate(d, blockIdx.y, 64, false, g, c0)) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0;
+    const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = c0 + 4 * cq;
+    const bool active = ch < mcp;
+    float2 c2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c2[j] = (active && ch + j < mc) ? bn_consts(stats2 + 2 * (size_t)(off + ch + j), 1.0 / ((double)d.N * HW), d.eps)
+                                        : make_float2(0.f, 0.f);
+    f32x4 g0 = zero4(), a1 = zero4(), b1 = zero4(), a2 = zero4(), b2 = zero4();
+    if (active) {
+        for (int hw = rl; hw < HW; hw += 64) {        // 4 independent rows in flight per thread
+            f32x4 v[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int h = hw + 16 * u;
+                const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
+                v[u] = ld4(D + a);
+                z[u] = ld4(dZ + a);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (hw + 16 * u < HW) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dh = (v[u][j] - c2[j].x) * c2[j].y;
+                        const float ad = act_d<ACT>(dh), zd = z[u][j] * ad;
+                        a1[j] += zd;
+                        b1[j] += zd * dh;
+                        if (has_se) {
+                            g0[j] += z[u][j] * act_f<ACT>(dh);
+                            a2[j] += ad;
+                            b2[j] += ad * dh;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const size_t NM = (size_t)d.N * M, o = (size_t)n * M + off + ch;
+    a1 = reduce_rows(a1, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) st4(pp + o, a1);
+    b1 = reduce_rows(b1, buf, rl, cq, 16, 16, active);
+    if (active && rl == 0) st4(pp + NM + o, b1);
+    if (has_se) {
+        a2 = reduce_rows(a2, buf, rl, cq, 16, 16, active);
+        if (active && rl == 0) st4(pp + 2 * NM + o, a2);
+        b2 = reduce_rows(b2, buf, rl, cq, 16, 16, active);
+        if (active && rl == 0) st4(pp + 3 * NM + o, b2);
+        g0 = reduce_rows(g0, buf, rl, cq, 16, 16, active);
+        if (active && rl == 0) st4(dgate + o, g0);
+    }
+}
+
+// red2[c] = (sum_n gate*A1 + dpooled/HW*A2, sum_n gate*B1 + dpooled/HW*B2) in double (non-SE groups: sum_n A1, sum_n B1)
+__global__ __launch_bounds__(256) void k_bn2_finish(TfnasCellDesc d, const float* __restrict__ pp,
+                                                    const float* __restrict__ gate, const float* __restrict__ dpooled,
+                                                    double* __restrict__ red2) {
+    __shared__ double sh[2][16][65];
+    int g, c0;
+    if (!chunk_locate(d, blockIdx.x, 64, false, g, c0)) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0;
+    const int M = d.M, N = d.N;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int ch = c0 + 4 * cq;
+    const bool active = ch < mcp;
+    const size_t NM = (size_t)N * M;
+    const float inv_hw = 1.f / (float)(d.Ho * d.Wo);
+    double r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+    if (active) {
+        for (int n = rl; n < N; n += 16) {
+            const size_t o = (size_t)n * M + off + ch;
+            f32x4 x1 = ld4(pp + o), y1 = ld4(pp + NM + o);
+            if (has_se) {
+                const f32x4 gt = ld4(gate + o), dp = ld4(dpooled + o) * splat4(inv_hw);
+                x1 = gt * x1 + dp * ld4(pp + 2 * NM + o);
+                y1 = gt * y1 + dp * ld4(pp + 3 * NM + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r1[j] += (double)x1[j];
+                r2[j] += (double)y1[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[0][rl][4 * cq + j] = r1[j];
+        sh[1][rl][4 * cq + j] = r2[j];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, cl = tid & 63;
+        if (c0 + cl < mc) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += sh[which][r][cl];
+            red2[2 * (size_t)(off + c0 + cl) + which] = t;
+        } else if (c0 + cl < mcp) {
+            red2[2 * (size_t)(off + c0 + cl) + which] = 0.0;
+        }
+    }
+}
+
 // ============================================================================ BN2 backward, pass 1
 // ddh = (dZ*gate + dpooled/HW) * act'(dhat) ;  red2[c] = (sum ddh, sum ddh*dhat)   (sums only: the consumers
 // k_dw_bwd_data / k_dw_wgrad recompute ddh from dZ in their tile loaders, so nothing is written back here)
@@ -470,6 +593,24 @@ int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, cons
     })
     _prof.stop();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, red2, nullptr, s);
+}
+
+// fused replacement of launch_se_bwd_reduce + launch_bn2_bwd (see k_bn2_pool); false if the [4][N][M] table does not fit
+bool bn2_fused_fits(const TfnasCellDesc& d) { return 4 * (size_t)d.N * d.M <= TFNAS_PART_FLOATS; }
+
+int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, float* dgate,
+                    float* pp, hipStream_t s) {
+    ProfScope _prof(TK_SE_BWD_REDUCE, s);
+    dim3 grid(d.N, chunk_count(d, 64, false));
+    ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_bn2_pool<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, dgate, pp); })
+    return (int)hipGetLastError();
+}
+
+int launch_bn2_finish(const TfnasCellDesc& d, const float* pp, const float* gate, const float* dpooled, double* red2,
+                      hipStream_t s) {
+    ProfScope _prof(TK_BN2_BWD, s);
+    hipLaunchKernelGGL(k_bn2_finish, dim3(chunk_count(d, 64, false)), dim3(256), 0, s, d, pp, gate, dpooled, red2);
+    return (int)hipGetLastError();
 }
 
 int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats1, float* pooled, hipStream_t s) {
