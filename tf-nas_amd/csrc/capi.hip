@@ -169,7 +169,7 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_expand_fwd(d, x, E, stats1, part, s));     // 1x1 expand (all groups) + BN1 statistics
     TRY(launch_dw_fwd(d, E, stats1, D, stats2, part, s)); // BN1+act fused load, depthwise, BN2 statistics
     TRY(launch_se_pool(d, D, stats2, pooled, s));         // SE squeeze (SE groups only)
-    TRY(launch_se_fc_fwd(d, pooled, hpre, gate, s));      // SE excite
+    TRY(launch_se_fc_fwd(d, pooled, hpre, gate, part, TFNAS_PART_FLOATS, s));      // SE excite (K-split partials in `part`)
     TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
     TRY(launch_mix_fwd(d, Pr, stats3, wmix, x, out, s));  // sum_g w_g BN3(.) + residual
     return 0;
@@ -221,7 +221,8 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     const bool fused2 = bn2_fused_fits(d);
     if (fused2) TRY(launch_bn2_pool(d, dZ, D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
     else TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
-    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, s));
+    // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
+    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, dEh, (size_t)d.N * d.H * d.W * d.M, s));
     if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, side_fork(sc, 1, s)));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));

@@ -33,7 +33,8 @@ int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, 
 // pointwise_kernels.hip (SE squeeze, BN2 backward statistics, mixing epilogue, BN constant tables)
 // se_kernels.hip (SE excite FCs as small GEMMs: launch_se_fc_fwd / launch_se_fc_bwd / launch_se_wgrad)
 int launch_se_pool(const TfnasCellDesc& d, const float* D, const double* stats2, float* pooled, hipStream_t s);
-int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s);
+int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, float* scratch,
+                     size_t scratch_floats, hipStream_t s);
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s);
 int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
@@ -42,7 +43,7 @@ int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resd
 int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2,
                          float* dgate, hipStream_t s);
 int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
-                     float* dgl, float* dhpre, float* dpooled, hipStream_t s);
+                     float* dgl, float* dhpre, float* dpooled, float* scratch, size_t scratch_floats, hipStream_t s);
 int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* dhpre,
                     const float* hpre, const float* pooled, hipStream_t s);
 bool bn2_fused_fits(const TfnasCellDesc& d);

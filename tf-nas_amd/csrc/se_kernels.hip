@@ -21,6 +21,9 @@ struct SeArgs {
     const float* dgate;    // [N][M]
     const float* dhpre;    // [N][SE]
     float* out0;           // mode-dependent output
+    float* scratch;        // MODE 0 / 2 with ksplit > 1: raw partial products [ksplit][N][SE]
+    int ksplit;            // K-splits of the long-K GEMMs (MODE 0 / 2): their output is only N x se, so without
+                           // splitting a handful of workgroups would each walk up to 72 K-chunks back to back
 };
 
 __device__ __forceinline__ int se_group_idx(const TfnasCellDesc& d, int idx) {
@@ -40,8 +43,12 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
     const int N = d.N, M = d.M, SE = d.SE;
     const bool mc_al = (mc & 3) == 0;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
-    const int r0 = blockIdx.x * 128;         // first GEMM row of this tile
+    const bool split = (MODE == 0 || MODE == 2) && a.ksplit > 1;
+    const int ks = split ? blockIdx.x % a.ksplit : 0;
+    const int r0 = (split ? blockIdx.x / a.ksplit : blockIdx.x) * 128;   // first GEMM row of this tile
     const int n0 = blockIdx.y * T::BN;       // first GEMM column
+    // chunk range of this K-split (MODE 0 / 2: K = mid channels)
+    const int cps = split ? (((mcp + 15) >> 4) + a.ksplit - 1) / a.ksplit : 0, cbase = ks * cps;
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
 
@@ -55,14 +62,15 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
     if (MODE == 0) {
         if (r0 >= N || n0 >= se) return;
         auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = c * 16 + kl;
+            const int n = r0 + row, k = (cbase + c) * 16 + kl;
             return (n < N && k < mcp) ? ld4(a.pooled + (size_t)n * M + off + k) : zero4();
         };
         auto fb = [&](int c, int nn, int kl) -> f32x4 {
-            const int j = n0 + nn, k = c * 16 + kl;
+            const int j = n0 + nn, k = (cbase + c) * 16 + kl;
             return (j < se) ? ld4_guard(d.g[g].w_se_r + (size_t)j * mc, k, mc, mc_al) : zero4();
         };
-        gemm_mainloop<NT, true, true>(fa, fb, (mcp + 15) >> 4, acc, lds);
+        const int tot = (mcp + 15) >> 4;
+        gemm_mainloop<NT, true, true>(fa, fb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 1) {
         if (r0 >= N || n0 >= mcp) return;
         auto fa = [&](int c, int row, int kl) -> f32x4 {
@@ -77,14 +85,15 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
     } else if (MODE == 2) {
         if (r0 >= N || n0 >= se) return;
         auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = c * 16 + kl;
+            const int n = r0 + row, k = (cbase + c) * 16 + kl;
             return (n < N && k < mcp) ? dgl4(n, k) : zero4();
         };
         auto fb = [&](int c, int kl, int nn) -> f32x4 {
-            const int k = c * 16 + kl, j = n0 + nn;
+            const int k = (cbase + c) * 16 + kl, j = n0 + nn;
             return (k < mc && j < se) ? ld4(d.g[g].w_se_e + (size_t)k * se + j) : zero4();
         };
-        gemm_mainloop<NT, true, false>(fa, fb, (mcp + 15) >> 4, acc, lds);
+        const int tot = (mcp + 15) >> 4;
+        gemm_mainloop<NT, true, false>(fa, fb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 3) {
         if (r0 >= N || n0 >= mcp) return;
         auto fa = [&](int c, int row, int kl) -> f32x4 {
@@ -120,7 +129,9 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
             for (int j = 0; j < NT; ++j) {
                 const int col = n0 + 16 * j + lr;
                 const float v = acc[i][j][r];
-                if (MODE == 0) {
+                if (split) {
+                    if (row < N && col < se) a.scratch[((size_t)ks * N + row) * SE + so + col] = v;
+                } else if (MODE == 0) {
                     if (row < N && col < se) a.out0[(size_t)row * SE + so + col] = v + d.g[g].b_se_r[col];
                 } else if (MODE == 1) {
                     if (row < N && col < mcp)
@@ -137,6 +148,26 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
                 }
             }
         }
+}
+
+// second stage of the K-split MODE 0 / 2 GEMMs: sum the splits (fixed order) and apply the epilogue
+//   MODE 0: hpre = sum + b_r          MODE 2: dhpre = sum * act'(hpre)
+template <int MODE, int ACT>
+__global__ __launch_bounds__(256) void k_se_finish(TfnasCellDesc d, SeArgs a) {
+    const int N = d.N, SE = d.SE;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * SE) return;
+    const int n = idx / SE, j = idx - n * SE;
+    float s = 0.f;
+    for (int k = 0; k < a.ksplit; ++k) s += a.scratch[((size_t)k * N + n) * SE + j];
+    if (MODE == 0) {
+        int g = 0;
+        for (; g < d.G; ++g)
+            if (d.g[g].se > 0 && j >= d.g[g].se_off && j < d.g[g].se_off + d.g[g].se) break;
+        a.out0[idx] = s + d.g[g].b_se_r[j - d.g[g].se_off];
+    } else {
+        a.out0[idx] = s * act_d<ACT>(a.hpre[idx]);
+    }
 }
 
 // bias gradients: gb_se_e[c] = sum_n dgl[n][c] ; gb_se_r[j] = sum_n dhpre[n][j]
@@ -196,36 +227,57 @@ static int se_count(const TfnasCellDesc& d, int& mcp_max, int& se_max) {
     return t;
 }
 
+// K-splits of MODE 0 / 2: >= 4 chunks of 16 channels per split, <= 16 splits, partials must fit `cap` floats
+static int se_ksplit(const TfnasCellDesc& d, int mcp_max, size_t cap) {
+    int ks = ((mcp_max + 15) / 16) / 4;
+    if (ks > 16) ks = 16;
+    const size_t per = (size_t)d.N * d.SE;
+    if (per && (size_t)ks > cap / per) ks = (int)(cap / per);
+    return ks < 1 ? 1 : ks;
+}
+
+#define SE_FINISH(MODE_)                                                                                 \
+    if (a.ksplit > 1) {                                                                                  \
+        dim3 fgrid(cdiv(d.N * d.SE, 256));                                                               \
+        if (d.act == TFNAS_ACT_RELU)                                                                     \
+            hipLaunchKernelGGL((k_se_finish<MODE_, TFNAS_ACT_RELU>), fgrid, dim3(256), 0, s, d, a);      \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_se_finish<MODE_, TFNAS_ACT_SWISH>), fgrid, dim3(256), 0, s, d, a);     \
+    }
+
 #define SE_LAUNCH(MODE_, rows, cols)                                                                     \
     {                                                                                                    \
-        dim3 grid(cdiv((rows), 128), cdiv((cols), 64), ng);                                              \
+        dim3 grid(cdiv((rows), 128) * (((MODE_) == 0 || (MODE_) == 2) ? a.ksplit : 1), cdiv((cols), 64), ng); \
         if (d.act == TFNAS_ACT_RELU)                                                                     \
             hipLaunchKernelGGL((k_se_gemm<MODE_, TFNAS_ACT_RELU>), grid, dim3(256), 0, s, d, a);         \
         else                                                                                             \
             hipLaunchKernelGGL((k_se_gemm<MODE_, TFNAS_ACT_SWISH>), grid, dim3(256), 0, s, d, a);        \
     }
 
-int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, hipStream_t s) {
+int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, float* gate, float* scratch,
+                     size_t scratch_floats, hipStream_t s) {
     ProfScope _prof(TK_SE_FC_FWD, s);
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
-    SeArgs a = {pooled, gate, hpre, nullptr, nullptr, hpre};
+    SeArgs a = {pooled, gate, hpre, nullptr, nullptr, hpre, scratch, se_ksplit(d, mcp_max, scratch ? scratch_floats : 0)};
     SE_LAUNCH(0, d.N, se_max)
+    SE_FINISH(0)
     a.out0 = gate;
     SE_LAUNCH(1, d.N, mcp_max)
     return (int)hipGetLastError();
 }
 
 int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* gate, const float* hpre,
-                     float* dgl, float* dhpre, float* dpooled, hipStream_t s) {
+                     float* dgl, float* dhpre, float* dpooled, float* scratch, size_t scratch_floats, hipStream_t s) {
     ProfScope _prof(TK_SE_FC_BWD, s);
     (void)dgl;
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
-    SeArgs a = {nullptr, gate, hpre, dgate, dhpre, dhpre};
+    SeArgs a = {nullptr, gate, hpre, dgate, dhpre, dhpre, scratch, se_ksplit(d, mcp_max, scratch ? scratch_floats : 0)};
     SE_LAUNCH(2, d.N, se_max)
+    SE_FINISH(2)
     a.out0 = dpooled;
     SE_LAUNCH(3, d.N, mcp_max)
     return (int)hipGetLastError();
@@ -237,7 +289,7 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gat
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
-    SeArgs a = {pooled, gate, hpre, dgate, dhpre, nullptr};
+    SeArgs a = {pooled, gate, hpre, dgate, dhpre, nullptr, nullptr, 1};
     SE_LAUNCH(4, mcp_max, se_max)
     SE_LAUNCH(5, mcp_max, se_max)
     hipLaunchKernelGGL(k_se_bias_grad, dim3(cdiv(mcp_max + se_max, 64), ng), dim3(256), 0, s, d, a);
