@@ -230,7 +230,12 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
-    if (dx && d.mode != TFNAS_MODE_STEM) TRY(launch_expand_dgrad(d, dEh, E, cb1, dout, wmix, dx, dxp, s));   // dx = de W_expand (+ residual)
+    if (dx && d.mode != TFNAS_MODE_STEM) {
+        // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
+        float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
+        TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
+        TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, dout, wmix, dx, dxp, s));
+    }
     return side_join(sc, s);
 }
 
@@ -255,7 +260,9 @@ extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const flo
     hipStream_t s = S(stream);
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));       // pool + swish backward, BN-backward sums
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
-    TRY(launch_expand_dgrad(d, dEh, E, cb1, nullptr, nullptr, dx, dxp, s));
+    float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
+    TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
+    TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, nullptr, nullptr, dx, dxp, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
 }

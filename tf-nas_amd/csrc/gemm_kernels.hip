@@ -301,14 +301,21 @@ __device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
     return r;
 }
 
-// ============================================================================ expand dgrad
-// dx[p][c] = sum_g sum_m de[p][off_g+m] * w_expand_g[m][c]  (+ sumw * dout[p][c] for residual cells)
-// K (= all mid channels of all groups, up to 6912) is split over blockIdx.z when the output grid alone cannot fill the
-// chip (7x7 / 14x14 cells: 49..196 row tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them.
+// ============================================================================ expand dgrad, without reading E
+// dx[p][c] = sum_m de[p][m] * W[m][c]  (+ sumw * dout[p][c] for residual cells),  m over all mid channels of all groups,
+//   de = rstd * (deh - t1 - ehat*t2),  ehat = (E - mu) * rstd,  (mu, rstd, t1, t2) = cb1[m]   (BN1 backward).
+// E is itself linear in x (E[p][m] = sum_c' x[p][c'] W[m][c']), so the ehat term collapses to an ic x ic operator:
+//   dx = deh (rstd.W)  -  x G  +  b,      G[c'][c] = sum_m W[m][c'] s_m W[m][c],   s_m = rstd_m^2 t2_m,
+//                                          b[c]    = sum_m (s_m mu_m - rstd_m t1_m) W[m][c].
+// The kernel therefore streams ONE [P][M] tensor (deh) with plain loads instead of two with a BN transform per element,
+// scales the (small) weight operand by rstd, and appends ceil(ic/16) K-chunks whose A operand is x and whose B operand
+// is -G; b is added in the epilogue.  G | b come from k_expand_gram ([ic+4][ic] floats, row ic = b).
+// K (up to 6912) is split over blockIdx.z when the output grid alone cannot fill the chip (7x7 / 14x14 cells: 49..196 row
+// tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them (and b, and the residual term).
 template <int NT>
 __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
-                                                      const float* __restrict__ E, const float* __restrict__ cb1,
-                                                      const float* __restrict__ dout,
+                                                      const float* __restrict__ x, const float* __restrict__ cb1,
+                                                      const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
                                                       float* __restrict__ dxp, int nsplit) {
     using T = GT<NT>;
@@ -316,8 +323,9 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
     const int n0 = blockIdx.y * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7;
-    int nchunks_all = 0;
-    for (int g = 0; g < d.G; ++g) nchunks_all += (d.g[g].mcp + 15) >> 4;
+    int mchunks = 0;
+    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    const int nchunks_all = mchunks + ((ic + 15) >> 4);      // mid-channel chunks, then the x / -G chunks
     const int per = (nchunks_all + nsplit - 1) / nsplit;
     const int cbeg = blockIdx.z * per;
     const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
@@ -333,8 +341,14 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
+        // chunk -> (group, first channel); g = -1: chunk of the x / -G part, k0 = first input channel
         auto locate = [&](int c, int& g, int& k0) {
             c += cbeg;
+            if (c >= mchunks) {
+                g = -1;
+                k0 = (c - mchunks) * 16;
+                return;
+            }
             g = 0;
             for (; g < d.G - 1; ++g) {
                 const int t = (d.g[g].mcp + 15) >> 4;
@@ -347,20 +361,23 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
             int g, k0;
             locate(c, g, k0);
             const int p = rt * 128 + row, k = k0 + kl;
-            if (p >= P || k >= d.g[g].mcp) return zero4();
-            const size_t col = (size_t)d.g[g].off + k;
-            return bn1_de(cb + col, ld4(dEh + (size_t)p * M + col), ld4(E + (size_t)p * M + col));
+            if (p >= P) return zero4();
+            if (g < 0) return k < ic ? ld4(x + (size_t)p * ic + k) : zero4();
+            return k < d.g[g].mcp ? ld4(dEh + (size_t)p * M + d.g[g].off + k) : zero4();
         };
         auto fb = [&](int c, int kl, int n) -> f32x4 {
             int g, k0;
             locate(c, g, k0);
             const int k = k0 + kl;
-            return (k < d.g[g].mc && n0 + n < ic) ? ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
+            if (n0 + n >= ic) return zero4();
+            if (g < 0) return k < ic ? -ld4(gram + (size_t)k * ic + n0 + n) : zero4();
+            return k < d.g[g].mc ? splat4(cb[d.g[g].off + k].y) * ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
         };
         gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow, c = n0 + lc;
             if (p < P && c < ic) {
+                if (nsplit == 1) v += ld4(gram + (size_t)ic * ic + c);
                 if (add_res) v += splat4(sumw) * ld4(dout + (size_t)p * d.oc + c);
                 st4(dst + (size_t)p * ic + c, v);
             }
@@ -368,21 +385,91 @@ __global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const flo
     }
 }
 
-// dx = sum_z dxp[z] (+ sumw * dout for residual cells)
+// dx = sum_z dxp[z] + b (+ sumw * dout for residual cells)
 __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float* __restrict__ dxp, int nsplit,
-                                                   const float* __restrict__ dout, const float* __restrict__ wmix,
-                                                   float* __restrict__ dx) {
+                                                   const float* __restrict__ gram, const float* __restrict__ dout,
+                                                   const float* __restrict__ wmix, float* __restrict__ dx) {
     const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
+    const int iq = d.ic / 4;
+    const float* __restrict__ bias = gram + (size_t)d.ic * d.ic;
     float sumw = 1.f;
     if (wmix) {
         sumw = 0.f;
         for (int g = 0; g < d.G; ++g) sumw += wmix[g];
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 v = d.has_res ? splat4(sumw) * ld4(dout + 4 * i) : zero4();
+        f32x4 v = ld4(bias + 4 * (int)(i % iq));
+        if (d.has_res) v += splat4(sumw) * ld4(dout + 4 * i);
         for (int z = 0; z < nsplit; ++z) v += ld4(dxp + (size_t)z * n4 * 4 + 4 * i);
         st4(dx + 4 * i, v);
     }
+}
+
+// ============================================================================ BN1-backward correction operator
+// part[split][(ic+4)*ic]:  rows c' < ic: G[c'][c] = sum_m W[m][c'] s_m W[m][c];  row ic: b[c] = sum_m coef_m W[m][c];
+// s_m = rstd_m^2 t2_m, coef_m = s_m mu_m - rstd_m t1_m   (see k_expand_dgrad).  GEMM rows = input channels (+ the b row),
+// columns = input channels, K = all mid channels of all groups, split over blockIdx.x (k_reduce_rows sums the splits).
+template <int NT>
+__global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const float* __restrict__ cb1, int chunks_per_split,
+                                                     float* __restrict__ part) {
+    using T = GT<NT>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    const int ic = d.ic;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.z * T::BN;
+    int mchunks = 0;
+    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    const int cbeg = blockIdx.x * chunks_per_split;
+    const int nchunks = max(0, min(mchunks, cbeg + chunks_per_split) - cbeg);
+    const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    float* __restrict__ out = part + (size_t)blockIdx.x * (size_t)(ic + 4) * ic;
+
+    f32x4 acc[2][NT];
+    acc_zero<NT>(acc);
+    auto locate = [&](int c, int& g, int& k0) {
+        c += cbeg;
+        g = 0;
+        for (; g < d.G - 1; ++g) {
+            const int t = (d.g[g].mcp + 15) >> 4;
+            if (c < t) break;
+            c -= t;
+        }
+        k0 = c * 16;
+    };
+    auto fa = [&](int c, int kl, int m) -> f32x4 {       // A(m..m+3, k) = s_k W[k][m..m+3]; row ic = coef_k
+        int g, k0;
+        locate(c, g, k0);
+        const int k = k0 + kl, r = m0 + m;
+        if (k >= d.g[g].mc || r > ic) return zero4();
+        const f32x4 t = cb[d.g[g].off + k];
+        const float sk = t.y * t.y * t.w;
+        if (r == ic) {
+            f32x4 v = zero4();
+            v.x = sk * t.x - t.y * t.z;
+            return v;
+        }
+        return splat4(sk) * ld4(d.g[g].w_expand + (size_t)k * ic + r);
+    };
+    auto fb = [&](int c, int kl, int n) -> f32x4 {
+        int g, k0;
+        locate(c, g, k0);
+        const int k = k0 + kl;
+        return (k < d.g[g].mc && n0 + n < ic) ? ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
+    };
+    gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wrow + 16 * i + 4 * lq + r;
+            if (row <= ic) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int cc = n0 + 16 * j + lr;
+                    if (cc < ic) out[(size_t)row * ic + cc] = acc[i][j][r];
+                }
+            }
+        }
 }
 
 // ============================================================================ expand wgrad (TN, split-K)
@@ -575,7 +662,32 @@ int expand_dgrad_splits(const TfnasCellDesc& d) {
     return ns < 1 ? 1 : ns;
 }
 
-int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+// floats of the correction operator G | b
+size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.ic + 4) * d.ic; }
+
+// G | b -> gram ([ic+4][ic] floats); `scratch` holds the K-split partials (scratch_floats available)
+int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
+                       hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    const int nt = pick_nt(d.ic, kNtSmall, 6);
+    const size_t gsz = expand_gram_floats(d);
+    int mchunks = 0;
+    for (int g = 0; g < d.G; ++g) mchunks += cdiv(d.g[g].mcp, 16);
+    const int mtiles = cdiv(d.ic + 1, 128), ntiles = cdiv(d.ic, 16 * nt);
+    int splits = cdiv(512, mtiles * ntiles);
+    if (splits > mchunks / 4) splits = mchunks / 4;               // at least 4 K-chunks per split
+    if ((size_t)splits > scratch_floats / gsz) splits = (int)(scratch_floats / gsz);
+    if (splits < 1) splits = 1;
+    if (scratch_floats < gsz) return TFNAS_ERANGE;
+    const int cps = cdiv(mchunks, splits);
+    splits = cdiv(mchunks, cps);
+    dim3 grid(splits, mtiles, ntiles);
+    DISPATCH_NT(nt, { hipLaunchKernelGGL(k_expand_gram<NT>, grid, dim3(256), 0, s, d, cb1, cps, scratch); })
+    _prof.stop();
+    return launch_reduce_rows(scratch, splits, (int)gsz, gsz, nullptr, gram, s);
+}
+
+int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
                         const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s) {
     ProfScope _prof(TK_EXPAND_DGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
@@ -583,7 +695,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit), tiles, nsplit);
     DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, E, cb1, dout, wmix, dx, dxp, nsplit);
+        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit);
     })
     _prof.stop();
     if (nsplit > 1) {
@@ -591,7 +703,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E
         const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
         size_t blocks = cdiv64(n4, 256 * 2);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, dout, wmix, dx);
+        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx);
     }
     return (int)hipGetLastError();
 }

@@ -13,7 +13,10 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s);
-int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
+size_t expand_gram_floats(const TfnasCellDesc& d);
+int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
+                       hipStream_t s);
+int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
                         const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s);
 int expand_dgrad_splits(const TfnasCellDesc& d);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
