@@ -179,6 +179,11 @@ int tfnas_arch_bwd(int ncell, const float *w, const float *lat, const float *dw,
 int tfnas_arch_sample(int ncell, const float *const *log_alpha, const uint8_t *mask, const float *e, float T,
                       int mode, int32_t *pos_out, void *stream);
 
+/* Projection of the architecture parameters after the Adam step (train_search.py:421-422):
+ *   p <- log_softmax(p) in place, for n 1-D fp32 device tensors of len[i] <= 8 elements each (log_alphas and betas),
+ * one launch for all of them.  p: n device pointers (host array), len: host int32[n]. */
+int tfnas_arch_project(int n, float *const *p, const int32_t *len, void *stream);
+
 /* Sink-connecting stage output (MixedStage.forward tail, models/model_search.py:202-204):
  *   bw = softmax(betas[K]);  out = sum_k bw[k]*res[k];  out_lat = sum_k bw[k]*(cell_lat[0]+..+cell_lat[k])
  * res: K device pointers to [count] floats each; cell_lat: device float[K] or NULL (sampled mode: lat 0).

@@ -218,6 +218,38 @@ int launch_arch_bwd(int ncell, const float* w, const float* lat, const float* dw
     return (int)hipGetLastError();
 }
 
+// p <- log_softmax(p) for up to TFNAS_MAX_CELLS small vectors: (x - max) - log(sum exp(x - max)), like torch's log_softmax
+struct ProjPack {
+    float* p[TFNAS_MAX_CELLS];
+    int len[TFNAS_MAX_CELLS];
+};
+__global__ void k_arch_project(int n, ProjPack pk) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float* __restrict__ x = pk.p[t];
+    const int len = pk.len[t];
+    float v[8], m = -INFINITY;
+    for (int i = 0; i < len; ++i) {
+        v[i] = x[i];
+        m = fmaxf(m, v[i]);
+    }
+    float s = 0.f;
+    for (int i = 0; i < len; ++i) s += expf(v[i] - m);
+    const float ls = logf(s);
+    for (int i = 0; i < len; ++i) x[i] = (v[i] - m) - ls;
+}
+
+int launch_arch_project(int n, float* const* p, const int32_t* len, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    ProjPack pk;
+    for (int i = 0; i < n; ++i) {
+        pk.p[i] = p[i];
+        pk.len[i] = len[i];
+    }
+    hipLaunchKernelGGL(k_arch_project, dim3(1), dim3(64), 0, s, n, pk);
+    return (int)hipGetLastError();
+}
+
 int launch_arch_sample(int ncell, const float* const* la, const uint8_t* mask, const float* e, float T, int mode,
                        int32_t* pos, hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);

@@ -281,6 +281,16 @@ extern "C" int tfnas_arch_bwd(int ncell, const float* w, const float* lat, const
     return launch_arch_bwd(ncell, w, lat, dw, dcell_lat, T, dlog_alpha, S(stream));
 }
 
+extern "C" int tfnas_arch_project(int n, float* const* p, const int32_t* len, void* stream) {
+    if (n < 1 || n > TFNAS_MAX_CELLS) return TFNAS_ERANGE;
+    if (!p || !len) return TFNAS_ENULL;
+    for (int i = 0; i < n; ++i) {
+        if (!p[i]) return TFNAS_ENULL;
+        if (len[i] < 1 || len[i] > 8) return TFNAS_ERANGE;
+    }
+    return launch_arch_project(n, p, len, S(stream));
+}
+
 extern "C" int tfnas_arch_sample(int ncell, const float* const* log_alpha, const uint8_t* mask, const float* e,
                                  float T, int mode, int32_t* pos_out, void* stream) {
     if (ncell < 1 || ncell > TFNAS_MAX_CELLS) return TFNAS_ERANGE;

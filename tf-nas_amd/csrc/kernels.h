@@ -71,6 +71,7 @@ int launch_arch_fwd(int ncell, const float* const* la, const float* e, const flo
                     float* cell_lat, hipStream_t s);
 int launch_arch_bwd(int ncell, const float* w, const float* lat, const float* dw, const float* dcl, float T,
                     float* const* dla, hipStream_t s);
+int launch_arch_project(int n, float* const* p, const int32_t* len, hipStream_t s);
 int launch_arch_sample(int ncell, const float* const* la, const uint8_t* mask, const float* e, float T, int mode,
                        int32_t* pos, hipStream_t s);
 int launch_sink_fwd(int K, const float* betas, const float* const* res, const float* cell_lat, uint64_t count,

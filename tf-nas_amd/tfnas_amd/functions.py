@@ -272,6 +272,22 @@ def arch_sample(log_alphas, masks, e, T, mode):
     return pos.cpu().tolist()
 
 
+def arch_project(params):
+    """In-place log_softmax of every architecture parameter (log_alphas and betas) in one launch; replaces the
+    per-parameter `p.data = F.log_softmax(p.data, dim=-1)` loop of train_search.py:421-422 (~3 kernels per parameter)."""
+    params = list(params)
+    lib = _lib.lib()
+    for i in range(0, len(params), 32):
+        chunk = params[i:i + 32]
+        for p in chunk:
+            _require_cuda(p, 'architecture parameter')
+            if p.dim() != 1 or p.numel() > 8 or not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError('tfnas_amd: architecture parameters must be contiguous 1-D fp32 tensors of <= 8 elements')
+        lens = (C.c_int32 * len(chunk))(*[p.numel() for p in chunk])
+        check(lib.tfnas_arch_project(len(chunk), ptr_array([p.data for p in chunk]), lens, _stream()),
+              'tfnas_arch_project')
+
+
 class SinkFn(torch.autograd.Function):
     """(out, out_lat) = softmax(betas)-weighted sum of the K depth outputs of a stage and of their cumulative
     latencies.  Replaces MixedStage.forward's tail (models/model_search.py:202-204)."""

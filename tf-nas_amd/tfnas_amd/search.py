@@ -17,10 +17,18 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .functions import arch_project
+
 
 def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-4, a_betas=(0.5, 0.999)):
     """train_search.py:197-206."""
     opt_w = torch.optim.SGD(model.weight_parameters(), lr=w_lr, momentum=w_mom, weight_decay=w_wd)
+    # Zero momentum buffers up front.  torch's multi-tensor SGD falls back to two tiny per-tensor kernels for EVERY
+    # parameter of a step as soon as one of them has no buffer yet -- which, with a freshly sampled sub-network per
+    # step, is the normal case for the first few hundred steps.  buf = 0*momentum + grad equals the first-step
+    # buf = clone(grad) bit for bit (dampening = 0), so the trajectory is unchanged.
+    for p in opt_w.param_groups[0]['params']:
+        opt_w.state[p]['momentum_buffer'] = torch.zeros_like(p)
     opt_a = torch.optim.Adam(model.arch_parameters(), lr=a_lr, betas=a_betas, weight_decay=a_wd)
     return opt_w, opt_a
 
@@ -140,8 +148,11 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     if grad_clip > 0:
         nn.utils.clip_grad_norm_(state.arch, grad_clip)
     opt_a.step()
-    for p in state.arch:
-        p.data = F.log_softmax(p.detach().data, dim=-1)
+    if state.arch[0].is_cuda:
+        arch_project(state.arch)                # p <- log_softmax(p) for all log_alphas and betas, one launch
+    else:                                       # (the step logic itself is model-agnostic: tests/test_dp_gloo.py drives it
+        for p in state.arch:                    #  with the CPU oracle model, whose parameters are host tensors)
+            p.data = F.log_softmax(p.detach().data, dim=-1)
     return loss_a.detach(), loss_l.detach(), lat.detach(), grads
 
 

@@ -39,6 +39,11 @@ def run(fn, label, n=4):
         fn()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n * 1e3
+    # host-side enqueue time of one call (returns before the GPU is done unless something inside synchronises)
+    t0 = time.perf_counter()
+    fn()
+    host = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
     lib.tfnas_prof_enable((1 << nf) - 1)
     for _ in range(n):
         fn()
@@ -46,7 +51,7 @@ def run(fn, label, n=4):
     fam = collect()
     lib.tfnas_prof_enable(0)
     tot = sum(v[1] for v in fam.values()) / n
-    print('%s: wall %.1f ms, HIP kernel families %.1f ms' % (label, wall, tot))
+    print('%s: wall %.1f ms, host enqueue %.1f ms, HIP kernel families %.1f ms' % (label, wall, host, tot))
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         if v[0]:
             print('   %-26s %7.3f ms  %5.1f launches  %6.1f us/launch' % (k, v[1] / n, v[0] / n, v[1] / v[0] * 1e3))
