@@ -302,11 +302,16 @@ class Network(nn.Module):
         else:
             raise ValueError('invalid sampling mode...')
 
-    def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None):
+    def stem_features(self, x):
+        """first_stem + second_stem output; may be passed back as ``forward(..., stem_out=)`` so that several forwards
+        of the same batch (the two sampled paths of a w-step) share one evaluation of the candidate-free stems."""
+        return self._stem(x)
+
+    def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None):
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
         # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per
         # iteration pair here: MIOpen's fp32 NHWC path falls back to naive_conv_*, torch's BN backward is slow)
-        x = self._stem(x)
+        x = self._stem(x) if stem_out is None else stem_out
         self._prepare(x, sampling, mode, exp_noise, rand_pos)
         for st in self.stages():
             x, lat = st(x, sampling, mode)

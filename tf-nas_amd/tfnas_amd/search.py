@@ -105,20 +105,31 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     backward -- runs concurrently with the 'gumbel' path.  Same arithmetic, same results."""
     model = state.model
     state.require(True, False)
-    logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g)
-    loss = F.cross_entropy(logits_g, target)
-    if bi_sampling and overlap_paths and x.is_cuda:
+    # The stems have no sampled candidates: both paths of bi-sampling see the same stem output (same input, same weights,
+    # same batch statistics), so it is computed once and fed to both (autograd sums the two paths' gradients into it);
+    # the reference runs the stems twice with identical results.  Only the HIP model exposes stem_features().
+    kw = {}
+    if bi_sampling and hasattr(model, 'stem_features'):
+        kw['stem_out'] = model.stem_features(x)
+    overlap = bi_sampling and overlap_paths and x.is_cuda
+    if overlap:
         cur = torch.cuda.current_stream(x.device)
         side = state.side_stream(x.device)
-        side.wait_stream(cur)                       # x, target and the weights are ready
-        with torch.cuda.stream(side):
-            logits_r, _ = model(x, True, 'random', rand_pos=rand_pos)
+        side.wait_stream(cur)                       # x, target, the weights and the stem output are ready: fork HERE, so
+                                                    # the side stream does not wait for the gumbel path's forward below
+    logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g, **kw)
+    loss = F.cross_entropy(logits_g, target)
+    if overlap:
+        with torch.cuda.stream(side):               # (its candidates depend on the gumbel pass's host-side choice only)
+            logits_r, _ = model(x, True, 'random', rand_pos=rand_pos, **kw)
             loss_r = F.cross_entropy(logits_r, target)
         cur.wait_stream(side)
         loss_r.record_stream(cur)
+        if 'stem_out' in kw:
+            kw['stem_out'].record_stream(side)
         loss = loss + loss_r
     elif bi_sampling:
-        logits_r, _ = model(x, True, 'random', rand_pos=rand_pos)
+        logits_r, _ = model(x, True, 'random', rand_pos=rand_pos, **kw)
         loss = loss + F.cross_entropy(logits_r, target)
     else:
         model.reset_switches()
