@@ -599,7 +599,7 @@ static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const dou
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
-int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
+static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
                        const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
                        float* part, hipStream_t s) {
