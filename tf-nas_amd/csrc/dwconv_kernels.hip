@@ -621,7 +621,7 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 
-int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
+static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
                     const double* stats2,
                     const double* red2, const float* E, const double* stats1, float* part, hipStream_t s) {
     size_t out_size = 0;
