@@ -25,6 +25,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'tf-nas_amd'))
 
+# The w-step keeps four HIP streams busy (two sampled paths x {data-gradient chain, weight-gradient side stream}).  The HIP
+# runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has created its own streams the
+# four compute streams no longer get a queue each and the w-step loses its overlap (24.4 -> 29.5 ms measured).  Must be set
+# before the first HIP call.
+if 'RANK' in os.environ:
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
