@@ -1,0 +1,130 @@
+"""Equivalence of the execution variants introduced for speed (all through the C ABI, fp32):
+row-streaming vs tiled depthwise kernels, weight-gradient side stream on/off, shared vs per-path stem evaluation,
+one-launch arch projection vs torch.log_softmax, K-split vs plain SE excite GEMMs.  A variant that only re-orders
+independent work must be bit-identical; one that changes a summation order must agree to fp32 rounding."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import tfnas_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r'''
+import os, sys
+ROOT = %r
+for p in ('', 'tf-nas_amd', 'oracle', 'tests'):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import torch
+import test_gpu_cell as t
+import _hipcheck as hc
+from tfnas_amd.functions import MixedOpFn
+out = {}
+for name in ('real_s1b2_56', 'real_s2b2_28', 'real_s4b2_14'):
+    cfg = [c for c in t.CONFIGS if c[0] == name][0]
+    for idxs, wg in ((list(range(8)), False), ([5], True), ([0], True)):
+        o, m, x, r, e = t._inputs(cfg)
+        plan = m._plan(tuple(idxs))
+        ps = plan.params()
+        for p in ps:
+            p.requires_grad_(wg)
+        xm = x.detach().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = torch.softmax(e[:8].detach().cuda(), 0).requires_grad_(True) if len(idxs) == 8 else None
+        y = MixedOpFn.apply(plan, xm, w, *ps)
+        (y * r.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        key = '%%s/%%s' %% (name, 'soft' if len(idxs) == 8 else 'op%%d' %% idxs[0])
+        out[key + '/out'] = y.detach().cpu()
+        out[key + '/dx'] = xm.grad.detach().cpu()
+        if wg:
+            for i, p in enumerate(ps):
+                out[key + '/g%%d' %% i] = p.grad.detach().cpu()
+torch.save(out, sys.argv[1])
+'''
+
+
+def _run_child(tmp_path, tag, env):
+    script = tmp_path / 'child.py'
+    script.write_text(_CHILD % ROOT)
+    out = tmp_path / ('%s.pt' % tag)
+    e = dict(os.environ)
+    e.update(env)
+    subprocess.run([sys.executable, str(script), str(out)], check=True, env=e, timeout=600)
+    return torch.load(out)
+
+
+def test_streaming_depthwise_equals_tiled_and_side_stream_is_bit_identical(tmp_path):
+    """The library reads its switches once per process, so each variant runs in a child process."""
+    base = _run_child(tmp_path, 'base', {})
+    tiled = _run_child(tmp_path, 'tiled', {'TFNAS_DW_TILED': '1'})
+    noside = _run_child(tmp_path, 'noside', {'TFNAS_WGRAD_STREAM': '0'})
+    assert base.keys() == tiled.keys() == noside.keys() and len(base) > 20
+    for k in base:
+        assert torch.equal(base[k], noside[k]), 'side stream changed %s' % k          # same kernels, other stream
+        a, b = base[k].double(), tiled[k].double()
+        tol = 2e-5 * float(b.abs().max()) + 1e-6                                        # other summation order only
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+
+
+def test_arch_project_matches_torch_log_softmax():
+    from tfnas_amd.functions import arch_project
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.randn(n, generator=g).mul_(3.0).cuda() for n in [8] * 18 + [1, 2, 3, 4, 4, 1]]
+    ref = [torch.log_softmax(p, dim=-1) for p in ps]
+    arch_project(ps)
+    torch.cuda.synchronize()
+    for p, r in zip(ps, ref):
+        assert float((p - r).abs().max()) <= 1e-6
+        assert abs(float(p.exp().sum()) - 1.0) <= 1e-5
+    with pytest.raises(RuntimeError):
+        arch_project([torch.zeros(9, device='cuda')])
+    with pytest.raises(RuntimeError):
+        arch_project([torch.zeros(4)])
+
+
+def test_shared_stem_is_bit_identical_to_per_path_stems():
+    """forward(x, stem_out=stem_features(x)) == forward(x), and a w-step with the shared stem equals one without."""
+    from tfnas_amd import Network, geometry, search
+    from tfnas_amd.latency import load_lat_lookup
+    lut = load_lat_lookup('gpu')
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 100, (4,), generator=g).cuda()
+    ng = torch.empty(18, 8).exponential_(generator=g).cuda()
+    rp = [3] * 18
+
+    def fresh():
+        torch.manual_seed(2)
+        m = Network(100, geometry.initial_mc_num_dddict(), lut).cuda()
+        m.set_temperature(5.0)
+        return m
+
+    m = fresh()
+    with torch.no_grad():
+        a, _ = m(x, True, 'max_alphas', stem_out=m.stem_features(x))
+        b, _ = m(x, True, 'max_alphas')
+    assert torch.equal(a, b)
+
+    res = []
+    cls = type(m)
+    saved = cls.stem_features
+    for share in (True, False):
+        m = fresh()
+        st = search.SearchState(m)
+        ow, _ = search.make_optimizers(m)
+        try:
+            if not share:
+                del cls.stem_features                     # w_step then evaluates the stems once per path
+            search.w_step(st, x, y, ow, 5.0, noise_g=ng, rand_pos=rp)
+        finally:
+            cls.stem_features = saved
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in m.weight_parameters()])
+    for p, q in zip(*res):
+        d = float((p - q).abs().max())
+        assert d <= 1e-6 + 1e-5 * float(q.abs().max()), d     # stem gradients: (g1 + g2) through one backward vs two
