@@ -106,10 +106,14 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     # The stems have no sampled candidates: both paths of bi-sampling see the same stem output (same input, same weights,
     # same batch statistics), so it is computed once and fed to both (autograd sums the two paths' gradients into it);
     # the reference runs the stems twice with identical results.  Only the HIP model exposes stem_features().
-    kw = {}
-    if bi_sampling and hasattr(model, 'stem_features'):
-        kw['stem_out'] = model.stem_features(x)
+    kw, feat, leaf = {}, None, None
     overlap = bi_sampling and overlap_paths and x.is_cuda
+    if bi_sampling and hasattr(model, 'stem_features'):
+        feat = model.stem_features(x)
+        # with two streams each path gets its own backward() call (below); the stem output is then a leaf whose two
+        # gradient contributions are summed before ONE backward through the stems
+        leaf = feat.detach().requires_grad_(True) if overlap else feat
+        kw['stem_out'] = leaf
     if overlap:
         cur = torch.cuda.current_stream(x.device)
         side = state.side_stream(x.device)
@@ -117,22 +121,31 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
                                                     # the side stream does not wait for the gumbel path's forward below
     logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g, **kw)
     loss = F.cross_entropy(logits_g, target)
+    opt_w.zero_grad()
     if overlap:
         with torch.cuda.stream(side):               # (its candidates depend on the gumbel pass's host-side choice only)
             logits_r, _ = model(x, True, 'random', rand_pos=rand_pos, **kw)
             loss_r = F.cross_entropy(logits_r, target)
+        # One backward() per path, the gumbel path first: a single backward over (loss + loss_r) would make the main stream
+        # wait for the random path's forward, and the autograd engine would enqueue the random path's whole backward
+        # before the first kernel of the gumbel path's (node order = creation order, newest first) although that path's
+        # forward finished long before -- the w-step's critical path is host enqueue time, not GPU time.
+        loss.backward()
+        with torch.cuda.stream(side):
+            loss_r.backward()
         cur.wait_stream(side)
         loss_r.record_stream(cur)
-        if 'stem_out' in kw:
-            kw['stem_out'].record_stream(side)
-        loss = loss + loss_r
-    elif bi_sampling:
-        logits_r, _ = model(x, True, 'random', rand_pos=rand_pos, **kw)
-        loss = loss + F.cross_entropy(logits_r, target)
+        if leaf is not None:
+            leaf.record_stream(side)
+            feat.backward(leaf.grad)
+        loss = loss.detach() + loss_r.detach()
     else:
-        model.reset_switches()
-    opt_w.zero_grad()
-    loss.backward()
+        if bi_sampling:
+            logits_r, _ = model(x, True, 'random', rand_pos=rand_pos, **kw)
+            loss = loss + F.cross_entropy(logits_r, target)
+        else:
+            model.reset_switches()
+        loss.backward()
     grads = [p.grad for p in state.weights if p.grad is not None]
     allreduce_mean_(grads, group)
     if grad_clip > 0:
