@@ -128,3 +128,45 @@ def test_shared_stem_is_bit_identical_to_per_path_stems():
     for p, q in zip(*res):
         d = float((p - q).abs().max())
         assert d <= 1e-6 + 1e-5 * float(q.abs().max()), d     # stem gradients: (g1 + g2) through one backward vs two
+
+
+def test_host_side_gumbel_sampling_equals_device_sampling_and_w_step():
+    """search.w_step samples the gumbel path on the host from a staged copy of the log_alphas when the noise comes from
+    NoiseSource; positions and the resulting step must equal the device-sampled ones."""
+    from tfnas_amd import Network, geometry, search
+    from tfnas_amd.functions import arch_sample
+    from tfnas_amd.latency import load_lat_lookup
+    g = torch.Generator().manual_seed(11)
+    for _ in range(50):
+        la = torch.log_softmax(torch.randn(18, 8, generator=g) * 2.0, -1)
+        e = torch.empty(18, 8).exponential_(generator=g)
+        host = search.host_gumbel_positions(la, e, 5.0)
+        devp = arch_sample([r.cuda() for r in la], [[1] * 8] * 18, e.cuda(), 5.0, 0)
+        assert host == devp
+    lut = load_lat_lookup('gpu')
+    x = torch.randn(4, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 100, (4,), generator=g).cuda()
+    res = []
+    for host_path in (True, False):
+        torch.manual_seed(2)
+        m = Network(100, geometry.initial_mc_num_dddict(), lut).cuda()
+        m.set_temperature(5.0)
+        with torch.no_grad():                                   # non-uniform alphas so that the choice is not trivial
+            for i, c in enumerate(m.cells()):
+                c.log_alphas.copy_(torch.log_softmax(torch.randn(8, generator=torch.Generator().manual_seed(i)), -1))
+        st = search.SearchState(m)
+        ow, _ = search.make_optimizers(m)
+        ns = search.NoiseSource(7)
+        idx = []
+        for it in range(2):
+            e = ns.exp(x.device)
+            rp = ns.rand_pos()
+            if not host_path:
+                e = e.clone()                                   # drops the host attribute -> device sampling
+            search.w_step(st, x, y, ow, 5.0, noise_g=e, rand_pos=rp)
+            idx.append([c.last_idx for c in m.cells()])
+        torch.cuda.synchronize()
+        res.append((idx, [p.detach().clone() for p in m.weight_parameters()]))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

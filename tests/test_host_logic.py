@@ -96,3 +96,16 @@ def test_product_package_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(import|from)\s+tfnas_oracle', src, flags=re.M), f
                 assert '/root/reference' not in src, f
+
+
+def test_host_gumbel_positions_match_the_oracle_cell_by_cell():
+    """search.host_gumbel_positions (vectorised over the cells) == the oracle MixedOP's own 'gumbel' choice."""
+    import torch
+    import tfnas_oracle as orc
+    from tfnas_amd import search
+    g = torch.Generator().manual_seed(5)
+    for _ in range(200):
+        la = torch.log_softmax(torch.randn(18, 8, generator=g) * 3.0, -1)
+        e = torch.empty(18, 8).exponential_(generator=g)
+        want = [int(torch.argmax(orc.gumbel_softmax(torch.log_softmax(la[c], -1), 5.0, e[c]))) for c in range(18)]
+        assert search.host_gumbel_positions(la, e, 5.0) == want

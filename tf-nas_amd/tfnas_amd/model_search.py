@@ -268,7 +268,7 @@ class Network(nn.Module):
             self._cells = [blk for st in self.stages() for blk in st.blocks()]
         return self._cells
 
-    def _prepare(self, x, sampling, mode, exp_noise, rand_pos):
+    def _prepare(self, x, sampling, mode, exp_noise, rand_pos, pos=None):
         """All arch-parameter work of one forward in ONE launch (and at most one device->host copy)."""
         cells = self.cells()
         n = len(cells)
@@ -290,6 +290,12 @@ class Network(nn.Module):
                 c._pre = (W[i], CL[i])
             return
         if mode in _SAMPLE_MODES:
+            if pos is not None:                       # positions already chosen (host-side sampling of search.w_step)
+                if len(pos) != n:
+                    raise ValueError('pos must hold one position per MixedOP')
+                for i, c in enumerate(cells):
+                    c._pre = c.sample_index(mode, pos=int(pos[i]))
+                return
             if mode.startswith('gumbel') and exp_noise is None:
                 exp_noise = torch.empty(n, 8, device=dev).exponential_()
             pos = arch_sample([c.log_alphas for c in cells], [[int(s) for s in c.switches] for c in cells],
@@ -307,12 +313,12 @@ class Network(nn.Module):
         of the same batch (the two sampled paths of a w-step) share one evaluation of the candidate-free stems."""
         return self._stem(x)
 
-    def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None):
+    def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None, pos=None):
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
         # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per
         # iteration pair here: MIOpen's fp32 NHWC path falls back to naive_conv_*, torch's BN backward is slow)
         x = self._stem(x) if stem_out is None else stem_out
-        self._prepare(x, sampling, mode, exp_noise, rand_pos)
+        self._prepare(x, sampling, mode, exp_noise, rand_pos, pos)
         for st in self.stages():
             x, lat = st(x, sampling, mode)
             out_lat += lat

@@ -42,12 +42,44 @@ class SearchState:
         self.arch = model.arch_parameters()
         self._mode = None
         self._side_stream = None
+        self._alpha_host = None            # (key, pinned [ncell, 8] copy of the log_alphas, copy-done event)
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (created once per device)."""
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=device)
         return self._side_stream
+
+    # -- host mirror of the log_alphas -------------------------------------------------------------------------
+    # The gumbel pass of a w-step needs the sampled candidate indices ON THE HOST (they decide which kernels are
+    # launched).  Sampling on the GPU costs a device->host copy that blocks until everything enqueued before it has
+    # finished, so the host can never run ahead of the GPU -- and the w-step is host-enqueue bound.  The log_alphas
+    # only change in the alpha-step, so a_step() stages a pinned host copy right after its projection and w_step()
+    # samples from that copy with the oracle's arithmetic (log_softmax -> gumbel_softmax -> argmax on the CPU).
+    def _alpha_key(self):
+        cells = self.model.cells()
+        return tuple((c.log_alphas.data_ptr(), c.log_alphas._version) for c in cells)
+
+    def stage_alpha_host(self):
+        cells = self.model.cells()
+        la = torch.stack([c.log_alphas.detach() for c in cells])
+        if not la.is_cuda:
+            self._alpha_host = (self._alpha_key(), la.clone(), None)
+            return
+        buf = torch.empty(la.shape, dtype=la.dtype, pin_memory=True)
+        buf.copy_(la, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(la.device))
+        self._alpha_host = (self._alpha_key(), buf, ev)
+
+    def alpha_host(self):
+        """Host copy of the log_alphas, or None when they were modified since it was staged."""
+        if self._alpha_host is None or self._alpha_host[0] != self._alpha_key():
+            self.stage_alpha_host()
+        _, buf, ev = self._alpha_host
+        if ev is not None:
+            ev.synchronize()
+        return buf
 
     def require(self, weights, arch):
         if self._mode != (weights, arch):
@@ -86,11 +118,21 @@ class NoiseSource:
         self.ncell = ncell
 
     def exp(self, device):
-        return torch.empty(self.ncell, 8).exponential_(generator=self.gen).to(device, non_blocking=True)
+        host = torch.empty(self.ncell, 8).exponential_(generator=self.gen)
+        dev = host.to(device, non_blocking=True)
+        dev._tfnas_host = host             # w_step samples the gumbel path on the host from these values
+        return dev
 
     def rand_pos(self):
         # position among the 7 candidates left after the gumbel pass (model_search.py:78-81)
         return [self.rng.randrange(7) for _ in range(self.ncell)]
+
+
+def host_gumbel_positions(log_alphas, exp_noise, T):
+    """argmax_i gumbel_softmax(log_softmax(log_alpha_c), T, e_c)_i for every cell (all switches on) -- the arithmetic of
+    MixedOP.forward's 'gumbel' mode (models/model_search.py:61-65) on host tensors."""
+    y = ((F.log_softmax(log_alphas, dim=-1) - exp_noise.log()) / T).softmax(-1)
+    return [int(v) for v in y.argmax(-1)]
 
 
 def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, bi_sampling=True, group=None,
@@ -119,7 +161,12 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
         side = state.side_stream(x.device)
         side.wait_stream(cur)                       # x, target, the weights and the stem output are ready: fork HERE, so
                                                     # the side stream does not wait for the gumbel path's forward below
-    logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g, **kw)
+    host_e = getattr(noise_g, '_tfnas_host', None)
+    if host_e is not None and hasattr(model, 'stem_features'):
+        T = model.cells()[0].T
+        logits_g, _ = model(x, True, 'gumbel', pos=host_gumbel_positions(state.alpha_host(), host_e, T), **kw)
+    else:
+        logits_g, _ = model(x, True, 'gumbel', exp_noise=noise_g, **kw)
     loss = F.cross_entropy(logits_g, target)
     opt_w.zero_grad()
     if overlap:
@@ -175,6 +222,8 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     else:                                       # (the step logic itself is model-agnostic: tests/test_dp_gloo.py drives it
         for p in state.arch:                    #  with the CPU oracle model, whose parameters are host tensors)
             p.data = F.log_softmax(p.detach().data, dim=-1)
+    if hasattr(model, 'stem_features'):
+        state.stage_alpha_host()                # async pinned copy for the next w-steps' host-side sampling
     return loss_a.detach(), loss_l.detach(), lat.detach(), grads
 
 
