@@ -13,6 +13,8 @@ Gradient clipping runs after the reduction, on the averaged gradients (train_sea
 """
 import random
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,6 +45,7 @@ class SearchState:
         self._mode = None
         self._side_stream = None
         self._alpha_host = None            # (key, pinned [ncell, 8] copy of the log_alphas, copy-done event)
+        self._step_done = []               # completion events of the most recent steps (bounds host run-ahead)
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (created once per device)."""
@@ -80,6 +83,23 @@ class SearchState:
         if ev is not None:
             ev.synchronize()
         return buf
+
+    def throttle(self, device, max_ahead=1):
+        """Without a device->host copy inside the steps nothing stops the host from enqueueing several steps ahead of
+        the GPU; the caching allocator then cannot recycle the previous steps' multi-GB workspaces (still in use by
+        pending kernels) and falls back to fresh hipMallocs, which stall for tens of ms.  Keep at most ``max_ahead``
+        steps in flight."""
+        if device.type != 'cuda':
+            return
+        while len(self._step_done) > max_ahead:
+            self._step_done.pop(0).synchronize()
+
+    def mark_step(self, device):
+        if device.type != 'cuda':
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._step_done.append(ev)
 
     def require(self, weights, arch):
         if self._mode != (weights, arch):
@@ -130,9 +150,18 @@ class NoiseSource:
 
 def host_gumbel_positions(log_alphas, exp_noise, T):
     """argmax_i gumbel_softmax(log_softmax(log_alpha_c), T, e_c)_i for every cell (all switches on) -- the arithmetic of
-    MixedOP.forward's 'gumbel' mode (models/model_search.py:61-65) on host tensors."""
-    y = ((F.log_softmax(log_alphas, dim=-1) - exp_noise.log()) / T).softmax(-1)
-    return [int(v) for v in y.argmax(-1)]
+    MixedOP.forward's 'gumbel' mode (models/model_search.py:61-65) on host data, in fp32 numpy.  (Not torch CPU ops:
+    with torch's default intra-op pool -- 128 OpenMP threads on the bench host -- even these 18x8-element ops wake the
+    whole pool, and its spinning workers stalled the launching thread for 50-250 ms every few steps.)"""
+    la = np.asarray(log_alphas, dtype=np.float32)
+    e = np.asarray(exp_noise, dtype=np.float32)
+    z = la - la.max(-1, keepdims=True)
+    ls = z - np.log(np.exp(z).sum(-1, keepdims=True, dtype=np.float32))
+    y = (ls - np.log(e)) / np.float32(T)
+    y = y - y.max(-1, keepdims=True)
+    p = np.exp(y)
+    p = p / p.sum(-1, keepdims=True, dtype=np.float32)
+    return [int(v) for v in p.argmax(-1)]
 
 
 def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, bi_sampling=True, group=None,
@@ -144,6 +173,7 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     second HIP stream, so its forward -- and, because autograd replays every node on its forward stream, its
     backward -- runs concurrently with the 'gumbel' path.  Same arithmetic, same results."""
     model = state.model
+    state.throttle(x.device)
     state.require(True, False)
     # The stems have no sampled candidates: both paths of bi-sampling see the same stem output (same input, same weights,
     # same batch statistics), so it is computed once and fed to both (autograd sums the two paths' gradients into it);
@@ -198,6 +228,7 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     if grad_clip > 0:
         nn.utils.clip_grad_norm_(state.weights, grad_clip)
     opt_w.step()
+    state.mark_step(x.device)
     return loss.detach(), logits_g.detach()
 
 
@@ -205,6 +236,7 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     """Architecture step: CE + lambda*|lat/target-1| -> backward -> (all-reduce) -> clip -> Adam -> log-softmax
     projection of alphas AND betas (train_search.py:421-422)."""
     model = state.model
+    state.throttle(x.device)
     state.require(False, True)
     logits, lat = model(x, False, exp_noise=noise)
     loss_a = F.cross_entropy(logits, target)
@@ -224,6 +256,7 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
             p.data = F.log_softmax(p.detach().data, dim=-1)
     if hasattr(model, 'stem_features'):
         state.stage_alpha_host()                # async pinned copy for the next w-steps' host-side sampling
+    state.mark_step(x.device)
     return loss_a.detach(), loss_l.detach(), lat.detach(), grads
 
 
