@@ -313,6 +313,42 @@ class Network(nn.Module):
         of the same batch (the two sampled paths of a w-step) share one evaluation of the candidate-free stems."""
         return self._stem(x)
 
+    def forward_bisample(self, x, pos_g, rand_pos, side_stream):
+        """Both sampled paths of a bi-sampling w-step in ONE sweep over the cells: the 'gumbel' candidate of a cell runs on
+        the current stream, its 'random' candidate on ``side_stream``, cell by cell.  Same kernels, same inputs and the
+        same per-cell switch bookkeeping as forward(x, True, 'gumbel', pos=pos_g) followed by
+        forward(x, True, 'random', rand_pos=rand_pos) -- but the host enqueues the two paths interleaved, so both streams
+        have work from the first cell on, and because autograd replays nodes newest-first the two paths' backward
+        passes are interleaved too (after the sequential forwards the whole backward of the second path is enqueued
+        before the first kernel of the first path's).  The stems are evaluated once.
+        Returns (logits_gumbel, logits_random); the second lives on ``side_stream``."""
+        cells = self.cells()
+        if len(pos_g) != len(cells) or len(rand_pos) != len(cells):
+            raise ValueError('pos_g / rand_pos must hold one entry per MixedOP')
+        cur = torch.cuda.current_stream(x.device)
+        feat = self._stem(x)
+        side_stream.wait_stream(cur)
+        feat.record_stream(side_stream)
+        xa = xb = feat
+        ci = 0
+        for st in self.stages():
+            ra, rb = [xa], [xb]
+            for blk in st.blocks():
+                ia = blk.sample_index('gumbel', pos=int(pos_g[ci]))
+                ib = blk.sample_index('random', rand_pos=rand_pos[ci])
+                blk.last_idx = ib                          # (what two sequential forwards leave behind)
+                ra.append(MixedOpFn.apply(blk._plan((ia,)), ra[-1], None, *blk.m_ops[ia].hip_params()))
+                with torch.cuda.stream(side_stream):
+                    rb.append(MixedOpFn.apply(blk._plan((ib,)), rb[-1], None, *blk.m_ops[ib].hip_params()))
+                ci += 1
+            xa, _ = SinkFn.apply(st.betas, None, *ra[st.start_res:])
+            with torch.cuda.stream(side_stream):
+                xb, _ = SinkFn.apply(st.betas, None, *rb[st.start_res:])
+        la = self.classifier(self._head(xa))
+        with torch.cuda.stream(side_stream):
+            lb = self.classifier(self._head(xb))
+        return la, lb
+
     def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None, pos=None):
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
         # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per

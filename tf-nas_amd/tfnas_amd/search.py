@@ -178,8 +178,30 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     # The stems have no sampled candidates: both paths of bi-sampling see the same stem output (same input, same weights,
     # same batch statistics), so it is computed once and fed to both (autograd sums the two paths' gradients into it);
     # the reference runs the stems twice with identical results.  Only the HIP model exposes stem_features().
-    kw, feat, leaf = {}, None, None
     overlap = bi_sampling and overlap_paths and x.is_cuda
+    host_e = getattr(noise_g, '_tfnas_host', None)
+    if overlap and host_e is not None and rand_pos is not None and hasattr(model, 'forward_bisample'):
+        # fast path: positions known on the host -> both paths in one interleaved sweep (see forward_bisample)
+        cur = torch.cuda.current_stream(x.device)
+        side = state.side_stream(x.device)
+        pos_g = host_gumbel_positions(state.alpha_host(), host_e, model.cells()[0].T)
+        logits_g, logits_r = model.forward_bisample(x, pos_g, rand_pos, side)
+        loss = F.cross_entropy(logits_g, target)
+        with torch.cuda.stream(side):
+            loss_r = F.cross_entropy(logits_r, target)
+        cur.wait_stream(side)
+        loss_r.record_stream(cur)
+        loss = loss + loss_r
+        opt_w.zero_grad()
+        loss.backward()
+        grads = [p.grad for p in state.weights if p.grad is not None]
+        allreduce_mean_(grads, group)
+        if grad_clip > 0:
+            nn.utils.clip_grad_norm_(state.weights, grad_clip)
+        opt_w.step()
+        state.mark_step(x.device)
+        return loss.detach(), logits_g.detach()
+    kw, feat, leaf = {}, None, None
     if bi_sampling and hasattr(model, 'stem_features'):
         feat = model.stem_features(x)
         # with two streams each path gets its own backward() call (below); the stem output is then a leaf whose two
@@ -191,7 +213,6 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
         side = state.side_stream(x.device)
         side.wait_stream(cur)                       # x, target, the weights and the stem output are ready: fork HERE, so
                                                     # the side stream does not wait for the gumbel path's forward below
-    host_e = getattr(noise_g, '_tfnas_host', None)
     if host_e is not None and hasattr(model, 'stem_features'):
         T = model.cells()[0].T
         logits_g, _ = model(x, True, 'gumbel', pos=host_gumbel_positions(state.alpha_host(), host_e, T), **kw)
