@@ -84,6 +84,13 @@ def test_error_codes(lib):
     assert lib.tfnas_mixedop_fwd(C.byref(d), None, None, None, None, None, None, None, None, None, None) == -2
     assert lib.tfnas_arch_fwd(0, None, None, None, 1.0, None, None, None) == -3
     assert lib.tfnas_sink_fwd(5, None, None, None, 8, None, None, None, None) == -3
+    # arch projection: count / pointer / length checks happen on the host
+    assert lib.tfnas_arch_project(0, None, None, None) == -3
+    assert lib.tfnas_arch_project(33, None, None, None) == -3
+    assert lib.tfnas_arch_project(1, None, None, None) == -2
+    one = (C.c_void_p * 1)(C.c_void_p(16))
+    assert lib.tfnas_arch_project(1, one, (C.c_int32 * 1)(9), None) == -3       # more than 8 elements
+    assert lib.tfnas_arch_project(1, (C.c_void_p * 1)(None), (C.c_int32 * 1)(8), None) == -2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
