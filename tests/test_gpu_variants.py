@@ -44,6 +44,31 @@ for name in ('real_s1b2_56', 'real_s2b2_28', 'real_s4b2_14'):
         if wg:
             for i, p in enumerate(ps):
                 out[key + '/g%%d' %% i] = p.grad.detach().cpu()
+# odd shapes for the row-streaming kernels: non-square images, more images than image lanes, ragged widths
+for si, (N, ic, oc, act, H, W) in enumerate([(3, 24, 24, 'swish', 17, 23), (9, 40, 40, 'swish', 56, 14),
+                                             (130, 16, 16, 'relu', 15, 20), (2, 40, 40, 'swish', 31, 55)]):
+    mids = [ic + v for v in (5, 29, 9, 83, 1, 19, 12, 28)]
+    o, m = hc.make_cell_pair(ic, oc, 1, act, mids, seed=si)
+    g = torch.Generator().manual_seed(100 + si)
+    x = torch.randn(N, ic, H, W, generator=g)
+    r = torch.randn(N, oc, H, W, generator=g)
+    e = torch.empty(8).exponential_(generator=g)
+    for idxs, wg in ((list(range(8)), False), ([3], True), ([4], True)):
+        plan = m._plan(tuple(idxs))
+        ps = plan.params()
+        for p in ps:
+            p.requires_grad_(wg)
+        xm = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = torch.softmax(e.cuda(), 0).requires_grad_(True) if len(idxs) == 8 else None
+        y = MixedOpFn.apply(plan, xm, w, *ps)
+        (y * r.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        key = 'odd%%d/%%s' %% (si, 'soft' if len(idxs) == 8 else 'op%%d' %% idxs[0])
+        out[key + '/out'] = y.detach().cpu()
+        out[key + '/dx'] = xm.grad.detach().cpu()
+        if wg:
+            for i, p in enumerate(ps):
+                out[key + '/g%%d' %% i] = p.grad.detach().cpu()
 torch.save(out, sys.argv[1])
 '''
 
