@@ -110,6 +110,8 @@ class SearchState:
             self._mode = (weights, arch)
 
 
+INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
+HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 FORCE_ALLREDUCE_AT_WORLD_1 = False     # bench.py sets this under torchrun so the RCCL path is exercised even on 1 GPU
 
 
@@ -179,8 +181,8 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     # same batch statistics), so it is computed once and fed to both (autograd sums the two paths' gradients into it);
     # the reference runs the stems twice with identical results.  Only the HIP model exposes stem_features().
     overlap = bi_sampling and overlap_paths and x.is_cuda
-    host_e = getattr(noise_g, '_tfnas_host', None)
-    if overlap and host_e is not None and rand_pos is not None and hasattr(model, 'forward_bisample'):
+    host_e = getattr(noise_g, '_tfnas_host', None) if HOST_SAMPLING else None
+    if INTERLEAVE_PATHS and overlap and host_e is not None and rand_pos is not None and hasattr(model, 'forward_bisample'):
         # fast path: positions known on the host -> both paths in one interleaved sweep (see forward_bisample)
         cur = torch.cuda.current_stream(x.device)
         side = state.side_stream(x.device)
