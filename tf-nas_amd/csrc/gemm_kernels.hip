@@ -4,6 +4,7 @@
 // Reference arithmetic: MBInvertedResBlock.forward, models/layers.py:539-561
 //   expand  = inverted_bottleneck.conv (layers.py:463-478)   project = point_linear.conv (layers.py:528-534)
 // and the autograd backward of those convolutions + BatchNorm2d(affine=False, batch stats).
+#include <stdlib.h>
 #include "gemm_core.h"
 #include "kernels.h"
 #include "prof.h"
@@ -78,8 +79,10 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
 // ============================================================================ project forward
 // Pr[g][p][o] = sum_c z_g[p][c] * w_proj_g[o][c],   z = act(BN2(D)) * gate   (fused into the A load)
 // epilogue: stats3[g][o] (BN3 batch statistics)
+// (launch bounds: the 7-tile variant otherwise takes 149 VGPRs + 56 AGPRs = 2 waves/SIMD, measured 1.5 resident; capping
+//  it at 168 registers buys the third wave: -17 % on the 112-channel cells)
 template <int NT, int ACT>
-__global__ __launch_bounds__(256) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 1) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
                                                      float* __restrict__ part) {
@@ -313,7 +316,7 @@ __device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
 // K (up to 6912) is split over blockIdx.z when the output grid alone cannot fill the chip (7x7 / 14x14 cells: 49..196 row
 // tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them (and b, and the residual term).
 template <int NT>
-__global__ __launch_bounds__(256) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 1) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ x, const float* __restrict__ cb1,
                                                       const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
