@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT, bool STEM>
-__global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 4) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
                                                     float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_expand_fwd(TfnasCellDesc d, const float
 // (launch bounds: the 7-tile variant otherwise takes 149 VGPRs + 56 AGPRs = 2 waves/SIMD, measured 1.5 resident; capping
 //  it at 168 registers buys the third wave: -17 % on the 112-channel cells)
 template <int NT, int ACT>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 1) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
                                                      float* __restrict__ part) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ f32x4 bn3_dp(const Bn3Tab& t, int o, f32x4 dout, f32x
 // ============================================================================ project dgrad
 // dZ[p][off_g + c] = sum_o dP_g[p][o] * w_proj_g[o][c]
 template <int NT>
-__global__ __launch_bounds__(256) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
                                                        const double* __restrict__ red3,
@@ -316,7 +316,7 @@ __device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
 // K (up to 6912) is split over blockIdx.z when the output grid alone cannot fill the chip (7x7 / 14x14 cells: 49..196 row
 // tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them (and b, and the residual term).
 template <int NT>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 1) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ x, const float* __restrict__ cb1,
                                                       const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
