@@ -275,19 +275,27 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
         return bn3_dp(tab, o, ld4(dout + (size_t)p * oc + o), ld4(Pr + ((size_t)g * Po + p) * oc + o));
     };
     gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+    // The gradient is [oc][mc] (mid channel fastest) and a lane's accumulator quad is 4 consecutive mid channels of one
+    // output channel: one 16-byte store per quad (the four lane groups of an output channel then cover 64 contiguous
+    // bytes) instead of four 4-byte stores that each scatter a wave over 64 different cache lines.
+    const bool vec = (mc & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int ch0 = m0 + wrow + 16 * i + 4 * lq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = m0 + wrow + 16 * i + 4 * lq + r;
-            if (ch < mc) {
+        for (int j = 0; j < NT; ++j) {
+            const int o = n0 + 16 * j + lr;
+            if (o >= oc) continue;
+            float* dst = gw + (size_t)o * mc + ch0;
+            if (vec && ch0 + 3 < mc) {
+                st4(dst, acc[i][j]);
+            } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int o = n0 + 16 * j + lr;
-                    if (o < oc) gw[(size_t)o * mc + ch] = acc[i][j][r];
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (ch0 + r < mc) dst[r] = acc[i][j][r];
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------- BN1-backward operand
