@@ -478,19 +478,24 @@ __global__ __launch_bounds__(256) void k_head_bwd(TfnasCellDesc d, const float* 
 }
 
 // ============================================================================ partials -> totals
-// out[c] = sum_{b < nb} part[b*stride + c]   (summed in double; 8 columns x 32 row-lanes per workgroup, 16 loads in
-// flight per thread, so up to 512 partial rows are folded in one round trip)
+// out[c] = sum_{b < nb} part[b*stride + c], summed in double in a fixed order (bit-reproducible).
+// k_reduce_rows<CL>: CL columns x (256/CL) row-lanes per workgroup, 16 loads in flight per thread -- for the statistics
+// partials (many rows, few columns: CL = 4 folds 1024 rows in one round trip and doubles the workgroup count of the
+// narrow sampled-mode launches).  k_reduce_rows_wide: 128 columns (float4 per thread) x 8 row-lanes -- for the split-K
+// weight-gradient partials (<= 128 rows of 10^4..10^5 columns), where the scalar version read 32-byte pieces of each row.
+template <int CL>
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int nb, int ncols, size_t stride,
                                                      double* __restrict__ out_d, float* __restrict__ out_f) {
-    __shared__ double buf[32][9];
-    const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    constexpr int RL = 256 / CL;
+    __shared__ double buf[RL][CL + 1];
+    const int tid = threadIdx.x, cl = tid % CL, rl = tid / CL;
+    const int c = blockIdx.x * CL + cl;
     double s = 0.0;
     if (c < ncols) {
-        for (int b = rl; b < nb; b += 512) {
+        for (int b = rl; b < nb; b += 16 * RL) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (b + 32 * u < nb) ? part[(size_t)(b + 32 * u) * stride + c] : 0.f;
+            for (int u = 0; u < 16; ++u) v[u] = (b + RL * u < nb) ? part[(size_t)(b + RL * u) * stride + c] : 0.f;
 #pragma unroll
             for (int u = 0; u < 16; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
         }
@@ -500,16 +505,51 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
     if (rl == 0 && c < ncols) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) t += buf[r][cl];
+        for (int r = 0; r < RL; ++r) t += buf[r][cl];
         if (out_d) out_d[c] = t;
         if (out_f) out_f[c] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_rows_wide(const float* __restrict__ part, int nb, int ncols, size_t stride,
+                                                          double* __restrict__ out_d, float* __restrict__ out_f) {
+    __shared__ double buf[8][128 + 4];
+    const int tid = threadIdx.x, cq = tid & 31, rl = tid >> 5;
+    const int c = blockIdx.x * 128 + 4 * cq;                  // ncols % 4 == 0: a quad is inside or outside as a whole
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < ncols) {
+        for (int b = rl; b < nb; b += 64) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (b + 8 * u < nb) ? ld4(part + (size_t)(b + 8 * u) * stride + c) : zero4();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s[j] += (((double)v[0][j] + (double)v[1][j]) + ((double)v[2][j] + (double)v[3][j])) +
+                        (((double)v[4][j] + (double)v[5][j]) + ((double)v[6][j] + (double)v[7][j]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) buf[rl][4 * cq + j] = s[j];
+    __syncthreads();
+    if (tid < 128 && blockIdx.x * 128 + tid < ncols) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += buf[r][tid];
+        if (out_d) out_d[blockIdx.x * 128 + tid] = t;
+        if (out_f) out_f[blockIdx.x * 128 + tid] = (float)t;
     }
 }
 
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(ncols, 8)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+    const bool al4 = (ncols & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)part & 15) == 0;
+    if (al4 && nb <= 128 && ncols >= 1024)
+        hipLaunchKernelGGL(k_reduce_rows_wide, dim3(cdiv(ncols, 128)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+    else if (ncols <= 2048 && nb > 256)
+        hipLaunchKernelGGL(k_reduce_rows<4>, dim3(cdiv(ncols, 4)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+    else
+        hipLaunchKernelGGL(k_reduce_rows<8>, dim3(cdiv(ncols, 8)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
     return (int)hipGetLastError();
 }
 
