@@ -127,6 +127,12 @@ int tfnas_cell_plan(TfnasCellDesc *d);
 /* Buffer sizes for a planned descriptor. */
 int tfnas_cell_ws(const TfnasCellDesc *d, TfnasCellWs *ws);
 
+/* 1 when the cell can run without the expanded tensor E ("E-free" mode: pass E = NULL to tfnas_mixedop_fwd AND to the
+ * matching tfnas_mixedop_bwd; the depthwise kernels then recompute act(BN1(x W_expand^T)) from the narrow cell input,
+ * and BN1's batch statistics come from the ic x ic Gram matrix of x).  Currently: TFNAS_MODE_CELL, need_wgrad = 0
+ * (the alpha-step: frozen weights), ic in {16, 24, 40}.  Same arithmetic contract as the E path (fp32, <= 1e-3). */
+int tfnas_efree_supported(const TfnasCellDesc *d);
+
 /* MixedOP forward.
  *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):
  *       out = sum_g wmix[g] * (BN3(project_g(SE_g(act(BN2(dw_g(act(BN1(expand_g(x))))))))) [+ x])

@@ -86,7 +86,7 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad):
     d, ws = dbg['d'], dbg['ws']
     N, H, W = x.shape[0], x.shape[2], x.shape[3]
     M, Ho, Wo = d.M, d.Ho, d.Wo
-    E = saved[2].view(N, H, W, M)
+    E = saved[2].view(N, H, W, M) if saved[2] is not None else None      # None: E-free mode (frozen weights)
     D = saved[3].view(N, Ho, Wo, M)
     Pr = saved[4].view(len(idxs), N, Ho, Wo, m.out_channels)
     fsmall = saved[5]
@@ -96,7 +96,8 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad):
     for g, (i, det) in enumerate(zip(idxs, details)):
         off, mc = d.g[g].off, d.g[g].mc
         tag = 'g%d.' % i
-        res[tag + 'E'] = err(E[..., off:off + mc], nhwc(det['E']))
+        if E is not None:
+            res[tag + 'E'] = err(E[..., off:off + mc], nhwc(det['E']))
         res[tag + 'D'] = err(D[..., off:off + mc], nhwc(det['D']))
         if 'gate' in det:
             res[tag + 'gate'] = err(gate[:, off:off + mc], det['gate'].flatten(1))

@@ -1,0 +1,104 @@
+"""E-free mode (include/tfnas_hip.h: tfnas_efree_supported; csrc/efree.h): with frozen weights the early cells
+(ic = 16 / 24 / 40) never materialise the expanded tensor E -- the depthwise kernels recompute act(BN1(x W^T)) from
+the cell input with MFMA and BN1's statistics come from the centred Gram matrix of x.  It must agree with the E path
+(same arithmetic up to fp32 summation order) and with the CPU oracle to the 1e-3 contract of the hot path."""
+import pytest
+import torch
+
+import _hipcheck as hc
+
+pytestmark = pytest.mark.gpu
+
+# (N, ic, oc, stride, act, H, W): the supernet's early-cell geometries at reduced size + ragged / odd shapes
+CASES = [
+    (4, 16, 24, 2, 'relu', 36, 44),
+    (3, 24, 24, 1, 'relu', 30, 26),
+    (5, 24, 40, 2, 'swish', 29, 23),
+    (2, 40, 40, 1, 'swish', 28, 28),
+    (9, 40, 80, 2, 'swish', 14, 17),
+    (130, 16, 16, 1, 'relu', 7, 9),
+]
+
+
+def _run(m, x, r, e, idxs, efree):
+    from tfnas_amd import functions as F
+    from tfnas_amd.functions import MixedOpFn
+    old = (F.EFREE, F.EFREE_STRIDE1)
+    F.EFREE, F.EFREE_STRIDE1 = efree, True
+    try:
+        plan = m._plan(tuple(idxs))
+        ps = plan.params()
+        for p in ps:
+            p.requires_grad_(False)
+        xm = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = torch.softmax(e.cuda(), 0).requires_grad_(True) if len(idxs) == 8 else None
+        y = MixedOpFn.apply(plan, xm, w, *ps)
+        used_efree = y.grad_fn.saved_tensors[2] is None
+        (y * r.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), xm.grad.detach(), (w.grad.detach() if w is not None else None), used_efree
+    finally:
+        F.EFREE, F.EFREE_STRIDE1 = old
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
+@pytest.mark.parametrize('idxs', [list(range(8)), [2], [5]], ids=['soft', 'op2', 'op5'])
+def test_efree_matches_e_path(case, idxs):
+    N, ic, oc, stride, act, H, W = case
+    mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
+    o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=ic + stride)
+    g = torch.Generator().manual_seed(7 * ic + H)
+    x = torch.randn(N, ic, H, W, generator=g) * 1.5 + 0.7          # non-zero channel means: the Gram path must centre
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, oc, Ho, Wo, generator=g)
+    e = torch.empty(8).exponential_(generator=g)
+    y0, dx0, dw0, used0 = _run(m, x, r, e, idxs, False)
+    y1, dx1, dw1, used1 = _run(m, x, r, e, idxs, True)
+    assert not used0 and used1
+    for a, b, name in ((y1, y0, 'out'), (dx1, dx0, 'dx'), (dw1, dw0, 'dwmix')):
+        if a is None:
+            continue
+        err, ref = hc.err(a, b)
+        assert err <= 2e-5 + 2e-4 * ref, (name, err, ref)
+
+
+@pytest.mark.parametrize('case', CASES[:5], ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
+def test_efree_matches_oracle_stage_by_stage(case):
+    N, ic, oc, stride, act, H, W = case
+    mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
+    o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=3)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, ic, H, W, generator=g) + 0.3
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, oc, Ho, Wo, generator=g)
+    e = torch.empty(8).exponential_(generator=g)
+    from tfnas_amd import functions as F
+    old = F.EFREE_STRIDE1
+    F.EFREE_STRIDE1 = True
+    try:
+        res = hc.compare_cell(o, m, x, r, e, list(range(8)), False)
+    finally:
+        F.EFREE_STRIDE1 = old
+    assert not any(k.endswith('.E') for k in res)                   # frozen weights -> E-free path was taken
+    assert not hc.worst(res), hc.worst(res)
+
+
+def test_efree_is_refused_when_unsupported():
+    """E = NULL with a geometry the E-free kernels do not cover (ic = 80) must fail loudly, not fall back."""
+    import ctypes as C
+    from tfnas_amd import _lib
+    mids = [80 * 3] * 8
+    o, m = hc.make_cell_pair(80, 80, 1, 'swish', mids, seed=1)
+    plan = m._plan(tuple(range(8)))
+    d, ws = plan.desc(2, 14, 14)
+    plan.bind(d, plan.params())
+    assert _lib.lib().tfnas_efree_supported(C.byref(d)) == 0
+    x = torch.zeros(2, 14, 14, 80, device='cuda')
+    bufs = [torch.zeros(int(n), device='cuda') for n in (ws.D, ws.Pr, ws.fsmall)]
+    stats = torch.zeros(int(ws.stats), device='cuda', dtype=torch.float64)
+    part = torch.zeros(int(ws.part), device='cuda')
+    out = torch.zeros(int(ws.out), device='cuda')
+    w = torch.full((8,), 0.125, device='cuda')
+    rc = _lib.lib().tfnas_mixedop_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(bufs[0]), _lib.ptr(bufs[1]),
+                                      _lib.ptr(bufs[2]), _lib.ptr(stats), _lib.ptr(part), _lib.ptr(out), None)
+    assert rc != 0

@@ -152,11 +152,14 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
         if (_r != 0) return _r; \
     } while (0)
 
+extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
+
 extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const float* wmix, float* E, float* D,
                                  float* Pr, float* fsmall, double* stats, float* part, float* out, void* stream) {
-    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
+    if (!dp || !x || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (!E && !efree_supported(d)) return TFNAS_ENULL;       // E may be omitted only in E-free mode (tfnas_efree_supported)
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
@@ -166,8 +169,9 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     float* pooled = fsmall + ws.off_pooled;
     float* gate = fsmall + ws.off_gate;
     float* hpre = fsmall + ws.off_hpre;
-    TRY(launch_expand_fwd(d, x, E, stats1, part, s));     // 1x1 expand (all groups) + BN1 statistics
-    TRY(launch_dw_fwd(d, E, stats1, D, stats2, part, s)); // BN1+act fused load, depthwise, BN2 statistics
+    if (E) TRY(launch_expand_fwd(d, x, E, stats1, part, s));          // 1x1 expand (all groups) + BN1 statistics
+    else TRY(launch_expand_stats_gram(d, x, stats1, part, s));        // E-free: BN1 statistics from the Gram matrix of x
+    TRY(launch_dw_fwd(d, E, x, stats1, D, stats2, part, s)); // BN1+act fused load, depthwise, BN2 statistics
     TRY(launch_se_pool(d, D, stats2, pooled, s));         // SE squeeze (SE groups only)
     TRY(launch_se_fc_fwd(d, pooled, hpre, gate, part, TFNAS_PART_FLOATS, s));      // SE excite (K-split partials in `part`)
     TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
@@ -179,10 +183,11 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
                                  const float* D, const float* Pr, const float* fsmall, const double* stats,
                                  const float* dout, float* dZ, float* dEh, float* bsmall, double* red, float* part,
                                  float* dx, float* dxp, float* dwmix, void* stream) {
-    if (!dp || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part)
+    if (!dp || !x || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part)
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (!E && !efree_supported(d)) return TFNAS_ENULL;
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
@@ -227,7 +232,7 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, side_fork(sc, 2, s)));
-    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
+    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, x, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
     TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
     if (dx && d.mode != TFNAS_MODE_STEM) {

@@ -15,6 +15,7 @@
 #include "tfnas_dev.h"
 #include "kernels.h"
 #include "prof.h"
+#include "efree.h"
 
 struct DwGeom {
     int T0, T1;        // tile height / width (in outputs for fwd & wgrad, in inputs for bwd-data)
@@ -141,8 +142,10 @@ __device__ __forceinline__ void load_tile(float* tile, int L0, int L1, int CC, i
 }
 
 // ============================================================================ forward
-template <int K, int S, int ACT>
+// KQ = 0: the tile is loaded from E.  KQ = ic/4 > 0 (E-free, efree.h): the tile is recomputed from the cell input x.
+template <int K, int S, int ACT, int KQ>
 __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float* __restrict__ E,
+                                                   const float* __restrict__ x,
                                                    const double* __restrict__ stats1, float* __restrict__ D,
                                                    float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -163,6 +166,11 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
         cst[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                    : make_float2(0.f, 0.f);
     stage_weights(wts, d.g[g].w_dw, K * K, CC, c0, mc);
+    ExpandB<(KQ > 0 ? KQ : 2)> xb;
+    if (KQ > 0) {
+        __syncthreads();
+        expand_b_load(xb, d.g[g].w_expand, d.ic, c0, mc, cst);
+    }
 
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
@@ -172,6 +180,15 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
         const int ho0 = th * TH, wo0 = tw * TW;
         const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
         __syncthreads();     // previous tile fully consumed (and cst/wts visible on the first pass)
+        if (KQ > 0) {
+            const float inv_iw = 1.f / (float)IW;
+            expand_tile<(KQ > 0 ? KQ : 2), ACT>(in_tile, IH * IW, CC, x, xb, [&](int p, size_t& a) {
+                const int r = (int)(((float)p + 0.5f) * inv_iw), c = p - r * IW;
+                const int hi = hi0 + r, wi = wi0 + c;
+                a = ((size_t)(n * H + hi) * W + wi) * d.ic;
+                return hi >= 0 && hi < H && wi >= 0 && wi < W;
+            });
+        } else
         load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
                   [&](int r, int c, int cq, size_t& a) {
                       const int hi = hi0 + r, wi = wi0 + c;
@@ -263,11 +280,14 @@ __device__ __forceinline__ void fill_cst2(f32x4* cst2, const TfnasCellDesc& d, i
 // ============================================================================ backward w.r.t. input
 // dA1[n][hi][wi][c] = sum_{ky,kx} dd[n][(hi+p-ky)/S][(wi+p-kx)/S][c] * w[c][ky][kx]   (only exact divisions)
 // epilogue: deh = dA1 * act'(ehat) -> dEh, and the BN1-backward sums (T1 = sum deh, T2 = sum deh*ehat)
-template <int K, int S, int ACT>
+// KQ > 0 (E-free, efree.h): ehat of the tile's input pixels is recomputed from x into a second LDS tile instead of
+// being read from E.
+template <int K, int S, int ACT, int KQ>
 __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const float* __restrict__ dZ,
                                                         const float* __restrict__ gate, const float* __restrict__ dpooled,
                                                         const float* __restrict__ D, const double* __restrict__ stats2,
                                                         const double* __restrict__ red2, const float* __restrict__ E,
+                                                        const float* __restrict__ x,
                                                         const double* __restrict__ stats1, float* __restrict__ dEh,
                                                         float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -291,6 +311,12 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
         cst1[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                     : make_float2(0.f, 0.f);
     stage_weights(wts, d.g[g].w_dw, K * K, CC, c0, mc);
+    float* eh_tile = reinterpret_cast<float*>(cst1 + CC);     // [TIH*TIW][CC] (E-free only)
+    ExpandB<(KQ > 0 ? KQ : 2)> xb;
+    if (KQ > 0) {
+        __syncthreads();
+        expand_b_load(xb, d.g[g].w_expand, d.ic, c0, mc, cst1);
+    }
 
     const int nsw = TIW >> 2, nstrips = TIH * nsw;
     const bool has_se = d.g[g].se > 0;
@@ -315,6 +341,15 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                        return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
                    },
                    [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd<ACT>(cst2, 4 * cq, v, dv, has_se, g4, dp4); });
+        if (KQ > 0) {
+            const float inv_iw = 1.f / (float)TIW;
+            expand_tile<(KQ > 0 ? KQ : 2), 2>(eh_tile, TIH * TIW, CC, x, xb, [&](int p, size_t& a) {
+                const int r = (int)(((float)p + 0.5f) * inv_iw), c = p - r * TIW;
+                const int hi = hi0 + r, wi = wi0 + c;
+                a = ((size_t)(n * H + hi) * W + wi) * d.ic;
+                return hi < H && wi < W;
+            });
+        }
         __syncthreads();
 
         for (int item = tid; item < nstrips * CQ; item += 256) {
@@ -328,7 +363,8 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
             for (int j = 0; j < 4; ++j) {
                 const int wi = wi0 + iw0 + j;
                 const bool okj = hi < H && wi < W && c0 + 4 * cq < mcp;
-                ev[j] = okj ? ld4(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq) : zero4();
+                if (KQ > 0) ev[j] = ld4(eh_tile + (ih * TIW + iw0 + j) * CC + 4 * cq);
+                else ev[j] = okj ? ld4(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq) : zero4();
             }
             if (S == 1) {
                 // column of output (wi + PAD - kx) relative to ow0 = wi0 + PAD - (K-1):  iw0 + j - kx + K - 1
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float2 c = cst1[4 * cq + q];
-                            const float eh = (e[q] - c.x) * c.y;
+                            const float eh = KQ > 0 ? e[q] : (e[q] - c.x) * c.y;
                             deh[q] = acc[j][q] * act_d<ACT>(eh);
                             t1[q] += deh[q];
                             t2[q] += deh[q] * eh;
@@ -514,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
 }
 
 // ============================================================================ host side
-static void pick_tile(int N, int Th, int Tw, int K, int S, bool fwd_like, DwGeom& gm) {
+// force32: the E-free producer (efree.h) works on 32-channel chunks
+static void pick_tile(int N, int Th, int Tw, int K, int S, bool fwd_like, DwGeom& gm, bool force32 = false) {
     // T1 (width) multiple of 4 (strips), up to 16; T0 so that a tile has ~128 (64 for stride 2) pixels
     gm.T1 = Tw >= 16 ? 16 : ((Tw + 3) / 4) * 4;
     const int target = (S == 2 && fwd_like) ? 64 : 128;
@@ -536,6 +573,7 @@ static void pick_tile(int N, int Th, int Tw, int K, int S, bool fwd_like, DwGeom
     gm.CC = 32;
     if (px * 32 * 4 > 56 * 1024) gm.CC = 16;
     else if (items32 < 192 && px * 64 * 4 <= 40 * 1024) gm.CC = 64;
+    if (force32) gm.CC = 32;
     gm.cq_shift = gm.CC == 16 ? 2 : gm.CC == 32 ? 3 : 4;
 }
 
@@ -552,6 +590,14 @@ static int dw_grid_x(const DwGeom& gm, int chunks, int target_blocks) {
     return gx < 1 ? 1 : gx;
 }
 
+#define KQ_DISPATCH(kq, ...)                                      \
+    switch (kq) {                                                 \
+        case 0: { constexpr int KQ = 0; __VA_ARGS__; } break;     \
+        case 4: { constexpr int KQ = 4; __VA_ARGS__; } break;     \
+        case 6: { constexpr int KQ = 6; __VA_ARGS__; } break;     \
+        case 10: { constexpr int KQ = 10; __VA_ARGS__; } break;   \
+        default: return TFNAS_EINVAL;                             \
+    }
 #define DW_DISPATCH(K_, S_, ACT_, ...)                                                         \
     if ((K_) == 3 && (S_) == 1 && (ACT_) == 0) { constexpr int K = 3, S = 1, ACT = 0; __VA_ARGS__; } \
     else if ((K_) == 3 && (S_) == 1) { constexpr int K = 3, S = 1, ACT = 1; __VA_ARGS__; }     \
@@ -563,11 +609,12 @@ static int dw_grid_x(const DwGeom& gm, int chunks, int target_blocks) {
     else { constexpr int K = 5, S = 2, ACT = 1; __VA_ARGS__; }
 
 // Both kernel-size passes of one stage share grid.x so that they fill the same rows of the partials matrix.
-static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, int target_blocks, size_t row_floats) {
+static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, int target_blocks, size_t row_floats,
+                        bool force32 = false) {
     int gx = 1 << 30;
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.N, Th, Tw, kk, d.stride, fwd_like, gm);
+        pick_tile(d.N, Th, Tw, kk, d.stride, fwd_like, gm, force32);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
         const int g1 = dw_grid_x(gm, chunks, target_blocks);
@@ -580,43 +627,53 @@ static int dw_common_gx(const TfnasCellDesc& d, int Th, int Tw, bool fwd_like, i
     return gx < 1 ? 1 : gx;
 }
 
-static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
-                              float* part, hipStream_t s) {
-    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M);
+// E == nullptr: E-free mode (the tile is recomputed from x, efree.h)
+static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const float* x, const double* stats1, float* D,
+                               double* stats2, float* part, hipStream_t s) {
+    const bool ef = E == nullptr;
+    if (ef && !efree_ic_ok(d.ic)) return TFNAS_EINVAL;
+    const int kq = ef ? d.ic / 4 : 0;
+    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M, ef);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm);
+        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm, ef);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
         const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
         ProfScope _prof(TK_DW_FWD, s);
-        DW_DISPATCH(kk, d.stride, d.act, {
-            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT>), grid, dim3(256), shm, s, d, E, stats1, D, part, gm);
-        })
+        if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
+        DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
+            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, E, x, stats1, D, part, gm);
+        }))
     }
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
 static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
-                       const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
+                       const double* red2, const float* E, const float* x, const double* stats1, float* dEh, double* red1,
                        float* part, hipStream_t s) {
-    const int gx = dw_common_gx(d, d.H, d.W, false, 4096, 2 * (size_t)d.M);
+    const bool ef = E == nullptr;
+    if (ef && !efree_ic_ok(d.ic)) return TFNAS_EINVAL;
+    const int kq = ef ? d.ic / 4 : 0;
+    const int gx = dw_common_gx(d, d.H, d.W, false, 4096, 2 * (size_t)d.M, ef);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.N, d.H, d.W, kk, d.stride, false, gm);
+        pick_tile(d.N, d.H, d.W, kk, d.stride, false, gm, ef);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
         const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
-        const size_t shm = (size_t)(tile + kk * kk * gm.CC + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
+        const size_t shm = (size_t)(tile + kk * kk * gm.CC + 4 * gm.CC + 2 * gm.CC + (ef ? gm.T0 * gm.T1 * gm.CC : 0)) *
+                           sizeof(float);
+        if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
         dim3 grid(gx, chunks);
         ProfScope _prof(TK_DW_BWD_DATA, s);
-        DW_DISPATCH(kk, d.stride, d.act, {
-            hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E,
-                               stats1, dEh, part, gm);
-        })
+        DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
+            hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2,
+                               red2, E, x, stats1, dEh, part, gm);
+        }))
     }
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }

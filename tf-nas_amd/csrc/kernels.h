@@ -23,12 +23,15 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
                         const float* x, float* part, hipStream_t s);
 
 // dwconv_kernels.hip
-int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
-                  float* part, hipStream_t s);
+// E == nullptr: E-free mode (efree.h) -- the expanded activation is recomputed from x inside the depthwise kernels
+int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const float* x, const double* stats1, float* D,
+                  double* stats2, float* part, hipStream_t s);
+bool efree_supported(const TfnasCellDesc& d);
+int launch_expand_stats_gram(const TfnasCellDesc& d, const float* x, double* stats1, float* part, hipStream_t s);
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
-                       const double* red2, const float* E, const double* stats1, float* dEh, double* red1,
-                       float* part, hipStream_t s);
+                       const double* red2, const float* E, const float* x, const double* stats1, float* dEh,
+                       double* red1, float* part, hipStream_t s);
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
                     const double* stats2,
                     const double* red2, const float* E, const double* stats1, float* part, hipStream_t s);

@@ -48,6 +48,7 @@ _PROTOS = {
     'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
+    'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_arch_project': (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),

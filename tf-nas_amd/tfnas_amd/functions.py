@@ -9,6 +9,7 @@ NHWC in HBM; ``_nhwc`` makes that view (zero-copy when the producer already wrot
 functions here do).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -16,6 +17,12 @@ from . import _lib
 from ._lib import TfnasCellDesc, TfnasCellWs, ptr, ptr_array, check
 
 BN_EPS = 1e-5
+# TFNAS_EFREE=0 keeps the expanded tensor E in every cell (A/B timing, equivalence tests)
+EFREE = os.environ.get('TFNAS_EFREE', '1') != '0'
+# default policy: stride-2 cells with ic <= 24 (cells 0 and 2 of the supernet, -25 % / -16 % of their alpha-step time).
+# The library also supports stride 1 and ic = 40, where the row-streaming kernels on a materialised E are still faster;
+# TFNAS_EFREE_STRIDE1=1 takes E-free wherever it is supported (tests).
+EFREE_STRIDE1 = os.environ.get('TFNAS_EFREE_STRIDE1', '0') == '1'
 
 
 def _stream():
@@ -94,7 +101,11 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
             raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
     plan.bind(d, params)
     dev = xh.device
-    E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+    # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
+    # cells never materialise the expanded tensor -- the depthwise kernels recompute it from x
+    efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and not any(ctx.needs_input_grad[3:])
+             and bool(_lib.lib().tfnas_efree_supported(C.byref(d))))
+    E = None if efree else torch.empty(ws.E, device=dev, dtype=torch.float32)
     D = torch.empty(ws.D, device=dev, dtype=torch.float32)
     Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
     fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
