@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
                                                    const double* __restrict__ stats1, float* __restrict__ D,
                                                    float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int g, c0;
-    if (!dw_locate<K>(d, blockIdx.y, gm.CC, g, c0)) return;
+    int g, c0, lane = blockIdx.x, cy = blockIdx.y;
+    if (KQ > 0) efree_lane_chunk(lane, cy);
+    if (!dw_locate<K>(d, cy, gm.CC, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const int CC = gm.CC, CQ = CC >> 2, TH = gm.T0, TW = gm.T1;
     const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, M = d.M;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
     f32x4 ssum = zero4(), ssq = zero4();
-    for (int t = xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
+    for (int t = KQ > 0 ? lane : xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int ho0 = th * TH, wo0 = tw * TW;
         const int hi0 = ho0 * S - K / 2, wi0 = wo0 * S - K / 2;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
             }
         }
     }
-    dw_flush_pair(ssum, ssq, in_tile, CC, c0, mcp, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off);
+    dw_flush_pair(ssum, ssq, in_tile, CC, c0, mcp, part + (size_t)lane * 2 * M + 2 * (size_t)off);
 }
 
 // ---------------------------------------------------------------------------- BN2-backward operand
@@ -291,8 +292,9 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                                                         const double* __restrict__ stats1, float* __restrict__ dEh,
                                                         float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int g, c0;
-    if (!dw_locate<K>(d, blockIdx.y, gm.CC, g, c0)) return;
+    int g, c0, lane = blockIdx.x, cy = blockIdx.y;
+    if (KQ > 0) efree_lane_chunk(lane, cy);
+    if (!dw_locate<K>(d, cy, gm.CC, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const int CC = gm.CC, CQ = CC >> 2, TIH = gm.T0, TIW = gm.T1;
     const int H = d.H, W = d.W, Ho = d.Ho, Wo = d.Wo, M = d.M;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
     const bool has_se = d.g[g].se > 0;
     const float inv_hw = 1.f / (float)(Ho * Wo);
     f32x4 t1 = zero4(), t2 = zero4();
-    for (int t = xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
+    for (int t = KQ > 0 ? lane : xcd_first_tile(); t < gm.ntiles; t += gridDim.x) {
         const int tw = t % gm.tilesW, th = (t / gm.tilesW) % gm.tilesH, n = t / (gm.tilesW * gm.tilesH);
         const int hi0 = th * TIH, wi0 = tw * TIW;
         const int oh0 = floordiv(hi0 + PAD - (K - 1), S), ow0 = floordiv(wi0 + PAD - (K - 1), S);
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
             }
         }
     }
-    dw_flush_pair(t1, t2, dd_tile, CC, c0, mcp, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off);
+    dw_flush_pair(t1, t2, dd_tile, CC, c0, mcp, part + (size_t)lane * 2 * M + 2 * (size_t)off);
 }
 
 // ============================================================================ weight gradient

@@ -99,4 +99,18 @@ __device__ __forceinline__ void expand_tile(float* tile, int npix, int CS, const
     }
 }
 
+// Workgroup -> (tile lane, channel chunk) for the E-free depthwise kernels, grid = (gx lanes, chunks).  All channel chunks
+// of a spatial tile re-read the same x pixels, so they should run at the same time on the SAME XCD (private L2): the
+// hardware deals workgroups round-robin to the 8 XCDs in x-fastest order, so XCD k is given the contiguous range
+// [k*total/8, (k+1)*total/8) of a chunk-fastest enumeration.  (With the plain (blockIdx.x, blockIdx.y) assignment every
+// chunk slab streamed all of x from HBM again: 18 x 103 MB for cell 0.)
+__device__ __forceinline__ void efree_lane_chunk(int& lane, int& cy) {
+    const int gx = gridDim.x, chunks = gridDim.y, total = gx * chunks;
+    const int L = blockIdx.x + gx * blockIdx.y;
+    const int xcd = L & 7, rem = total & 7;
+    const int V = xcd * (total >> 3) + (xcd < rem ? xcd : rem) + (L >> 3);
+    lane = V / chunks;
+    cy = V - lane * chunks;
+}
+
 static inline bool efree_ic_ok(int ic) { return ic == 16 || ic == 24 || ic == 40; }
