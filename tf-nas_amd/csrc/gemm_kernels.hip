@@ -566,15 +566,38 @@ static size_t stats_row_cap(size_t row_floats) {
     return fit < 1024 ? fit : 1024;
 }
 
-// number of persistent row-blocks: ~4096 workgroups in total, and (for kernels with a statistics epilogue)
-// at most `cap` so that the per-workgroup partials fit the scratch buffer
-static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30) {
+// Number of persistent row blocks (grid.x) of a row-tiled GEMM launch.  The launch runs gx * other workgroups on
+// `slots` resident workgroup slots (256 CUs x 3 or 4 per CU, set by the kernel's launch bounds) and each workgroup walks
+// ceil(nrt / gx) row tiles, so the launch takes about ceil(gx*other / slots) * ceil(nrt / gx) tile times.  The old rule
+// (~4096 workgroups in total) left the 14x14 / 7x7 cells with a nearly empty last round (e.g. 2.04 rounds -> 3: 68 %
+// efficient); this picks the gx that minimises the product, the larger gx on ties (finer dynamic balancing), subject to
+// `cap` (partial rows of the statistics epilogues must fit the scratch buffer and stay <= 1024).
+static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30, int slots = 1024, int max_gx = 1024) {
     const int nrt = cdiv(rows, 128);
-    int want = cdiv(4096, other_blocks > 0 ? other_blocks : 1);   // ~16 workgroups per CU in total
-    if ((size_t)want > cap) want = (int)cap;
-    if (want < 1) want = 1;
-    return nrt < want ? nrt : want;
+    const int other = other_blocks > 0 ? other_blocks : 1;
+    int lim = nrt;
+    if ((size_t)lim > cap) lim = (int)cap;
+    if (lim > max_gx) lim = max_gx;                    // (bounds the host-side search; measured per kernel family)
+    if (lim < 1) lim = 1;
+    static const char* legacy = getenv("TFNAS_ROWBLOCKS_LEGACY");
+    if (legacy && legacy[0] == '1') {
+        int want = cdiv(4096, other);
+        if ((size_t)want > cap) want = (int)cap;
+        if (want < 1) want = 1;
+        return nrt < want ? nrt : want;
+    }
+    long best_cost = -1;
+    int best = 1;
+    for (int gx = 1; gx <= lim; ++gx) {
+        const long cost = (long)cdiv(gx * other, slots) * cdiv(nrt, gx);
+        if (best_cost < 0 || cost <= best_cost) {
+            best_cost = cost;
+            best = gx;
+        }
+    }
+    return best;
 }
+static inline int gemm_slots(int nt) { return 256 * (nt >= 5 ? 3 : 4); }
 
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
                       hipStream_t s) {
@@ -599,7 +622,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int tiles = cdiv(d.oc, 16 * nt);
     const int ncols2 = 2 * d.G * d.oc;
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, stats_row_cap((size_t)ncols2)), tiles, d.G);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt)), tiles, d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part);
@@ -614,7 +637,7 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
     constexpr int NT = 4;
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles), tiles);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(NT)), tiles);
     const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
     hipLaunchKernelGGL(k_project_dgrad<NT>, grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
     return (int)hipGetLastError();
@@ -704,7 +727,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit), tiles, nsplit);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit, 1u << 30, gemm_slots(nt), 4096), tiles, nsplit);
     DISPATCH_NT(nt, {
         hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit);
     })
