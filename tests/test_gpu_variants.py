@@ -96,6 +96,17 @@ def test_streaming_depthwise_equals_tiled_and_side_stream_is_bit_identical(tmp_p
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
 
 
+def test_fused_se_excite_equals_gemm_path(tmp_path):
+    """Per-image fused excite kernels (default) vs the MFMA GEMM formulation (TFNAS_SE_GEMM=1): other summation order."""
+    base = _run_child(tmp_path, 'base', {})
+    gemm = _run_child(tmp_path, 'segemm', {'TFNAS_SE_GEMM': '1'})
+    assert base.keys() == gemm.keys() and len(base) > 20
+    for k in base:
+        a, b = base[k].double(), gemm[k].double()
+        tol = 5e-5 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+
+
 def test_arch_project_matches_torch_log_softmax():
     from tfnas_amd.functions import arch_project
     g = torch.Generator().manual_seed(3)

@@ -214,6 +214,177 @@ __global__ __launch_bounds__(256) void k_se_bias_grad(TfnasCellDesc d, SeArgs a)
     }
 }
 
+// ============================================================================ fused excite stage (forward / backward)
+// One workgroup per (image, SE group) runs BOTH 1x1 convolutions of that image: the pooled row lives in LDS, the hidden
+// vector never leaves the workgroup.  The excite stage is ~1 MFLOP per image -- as GEMMs it was 2-3 dependent launches
+// (K-split MODE 0 + finish + MODE 1) of mostly empty MFMA tiles, 30-50 us on the critical path of every cell; here it is
+// one launch whose time is a few L2 round trips.  Plain fp32 FMA chains (fixed order: bit-reproducible).
+// Stage `rows` rows of a row-major [.][se] matrix (starting at row c0) into LDS with an odd row stride (se | 1), so that
+// thread-per-row and thread-per-column walks are both bank-conflict free.  The global side is one contiguous block.
+__device__ __forceinline__ void se_stage_rows(float* wl, const float* __restrict__ w, int c0, int rows, int se, int ld) {
+    const int n = rows * se;
+    const float* __restrict__ src = w + (size_t)c0 * se;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = i / se, j = i - r * se;
+        wl[r * ld + j] = src[i];
+    }
+}
+
+constexpr int SE_CH = 128;   // channels per staged block of W_e
+
+template <int ACT>
+__global__ __launch_bounds__(256) void k_se_fused_fwd(TfnasCellDesc d, const float* __restrict__ pooled,
+                                                      float* __restrict__ hpre, float* __restrict__ gate) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int g = se_group_idx(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int n = blockIdx.x, M = d.M, SE = d.SE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mcq = (mcp + 3) & ~3, ld = se | 1;
+    float* ps = sm;                  // [mcq] pooled row
+    float* hs = sm + mcq;            // [se]  act(hpre)
+    float* wl = hs + ((se + 3) & ~3);   // [SE_CH][ld] block of W_e
+    for (int c = tid; c < mcq; c += 256) ps[c] = c < mc ? pooled[(size_t)n * M + off + c] : 0.f;
+    __syncthreads();
+    // hidden units: one wave per row of W_r, three rows in flight (rows are contiguous: coalesced 16-byte loads)
+    const bool al = (mc & 3) == 0;
+    for (int j0 = wave; j0 < se; j0 += 12) {
+        float s[3] = {0.f, 0.f, 0.f};
+        if (al) {
+            for (int c = 4 * lane; c < mc; c += 256) {
+                const f32x4 p4 = ld4(ps + c);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int j = j0 + 4 * r;
+                    if (j < se) {
+                        const f32x4 w4 = ld4(d.g[g].w_se_r + (size_t)j * mc + c);
+                        s[r] += (w4.x * p4.x + w4.y * p4.y) + (w4.z * p4.z + w4.w * p4.w);
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < mc; c += 64) {
+                const float p = ps[c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int j = j0 + 4 * r;
+                    if (j < se) s[r] += d.g[g].w_se_r[(size_t)j * mc + c] * p;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int j = j0 + 4 * r;
+            if (j < se) {
+                const float v = wave_sum(s[r]) + d.g[g].b_se_r[j];
+                if (lane == 0) {
+                    hpre[(size_t)n * SE + so + j] = v;
+                    hs[j] = act_f<ACT>(v);
+                }
+            }
+        }
+    }
+    // gate: W_e is [mc][se]; blocks of SE_CH rows go through LDS, two threads per channel (even / odd hidden units)
+    for (int c0 = 0; c0 < mcp; c0 += SE_CH) {
+        const int rows = min(SE_CH, mc - c0);
+        __syncthreads();                                   // hs complete / previous block consumed
+        if (rows > 0) se_stage_rows(wl, d.g[g].w_se_e, c0, rows, se, ld);
+        __syncthreads();
+        const int cl = tid >> 1, half = tid & 1, c = c0 + cl;
+        float sacc = 0.f;
+        if (cl < rows) {
+            const float* row = wl + cl * ld;
+            for (int j = half; j < se; j += 2) sacc += row[j] * hs[j];
+        }
+        sacc += __shfl_xor(sacc, 1, 64);
+        if (half == 0 && c < mcp) gate[(size_t)n * M + off + c] = c < mc ? sigmoid_f(sacc + d.g[g].b_se_e[c]) : 0.f;
+    }
+}
+
+// dgl = dgate*gate*(1-gate);  dhpre = (dgl W_e) * act'(hpre);  dpooled = dhpre W_r
+template <int ACT>
+__global__ __launch_bounds__(256) void k_se_fused_bwd(TfnasCellDesc d, const float* __restrict__ dgate,
+                                                      const float* __restrict__ gate, const float* __restrict__ hpre,
+                                                      float* __restrict__ dhpre, float* __restrict__ dpooled) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int g = se_group_idx(d, blockIdx.y);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int n = blockIdx.x, M = d.M, SE = d.SE;
+    const int tid = threadIdx.x;
+    const int mcq = (mcp + 3) & ~3, ld = se | 1, seq = (se + 3) & ~3;
+    float* dgl = sm;                 // [mcq]
+    float* dhs = sm + mcq;           // [seq]
+    float* red = dhs + seq;          // [256]
+    float* wl = red + 256;           // [SE_CH][ld]
+    for (int c = tid; c < mcq; c += 256) {
+        float v = 0.f;
+        if (c < mc) {
+            const float gt = gate[(size_t)n * M + off + c];
+            v = dgate[(size_t)n * M + off + c] * gt * (1.f - gt);
+        }
+        dgl[c] = v;
+    }
+    // dh[j] = sum_c dgl[c] W_e[c][j]: thread = (hidden unit j, channel phase); W_e blocks staged in LDS
+    const int sep = se < 256 ? se : 256, nph = 256 / sep;       // phases per hidden unit
+    const int jj = tid % sep, ph = tid / sep;
+    float dh = 0.f;
+    for (int c0 = 0; c0 < mc; c0 += SE_CH) {
+        const int rows = min(SE_CH, mc - c0);
+        __syncthreads();
+        se_stage_rows(wl, d.g[g].w_se_e, c0, rows, se, ld);
+        __syncthreads();
+        if (ph < nph)
+            for (int j = jj; j < se; j += sep)                  // (se > 256: several units per thread, same phase)
+                for (int cl = ph; cl < rows; cl += nph) dh += dgl[c0 + cl] * wl[cl * ld + j];
+    }
+    red[tid] = dh;
+    __syncthreads();
+    for (int j = tid; j < se && j < sep; j += 256) {
+        float t = 0.f;
+        for (int p = 0; p < nph; ++p) t += red[p * sep + j];
+        const float v = t * act_d<ACT>(hpre[(size_t)n * SE + so + j]);
+        dhs[j] = v;
+        dhpre[(size_t)n * SE + so + j] = v;
+    }
+    __syncthreads();
+    // dpooled[c] = sum_j dhs[j] W_r[j][c]: coalesced over c, 8 rows in flight
+    const bool al = (mc & 3) == 0;
+    if (al) {
+        for (int c = 4 * tid; c < mcq; c += 1024) {
+            f32x4 acc = zero4();
+            if (c < mc) {
+                const float* __restrict__ wr = d.g[g].w_se_r + c;
+                int j = 0;
+                for (; j + 7 < se; j += 8) {
+                    f32x4 w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w[u] = ld4(wr + (size_t)(j + u) * mc);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += w[u] * splat4(dhs[j + u]);
+                }
+                for (; j < se; ++j) acc += ld4(wr + (size_t)j * mc) * splat4(dhs[j]);
+            }
+            if (c < mcp) st4(dpooled + (size_t)n * M + off + c, acc);
+        }
+    } else {
+        for (int c = tid; c < mcp; c += 256) {
+            float s0 = 0.f, s1 = 0.f;
+            if (c < mc) {
+                const float* __restrict__ wr = d.g[g].w_se_r + c;
+                int j = 0;
+                for (; j + 1 < se; j += 2) {
+                    s0 += dhs[j] * wr[(size_t)j * mc];
+                    s1 += dhs[j + 1] * wr[(size_t)(j + 1) * mc];
+                }
+                if (j < se) s0 += dhs[j] * wr[(size_t)j * mc];
+            }
+            dpooled[(size_t)n * M + off + c] = s0 + s1;
+        }
+    }
+}
+
 // ============================================================================ host launchers
 static int se_count(const TfnasCellDesc& d, int& mcp_max, int& se_max) {
     int t = 0;
@@ -234,6 +405,16 @@ static int se_ksplit(const TfnasCellDesc& d, int mcp_max, size_t cap) {
     const size_t per = (size_t)d.N * d.SE;
     if (per && (size_t)ks > cap / per) ks = (int)(cap / per);
     return ks < 1 ? 1 : ks;
+}
+
+// the fused per-image kernels need the pooled row + hidden vectors in LDS; TFNAS_SE_GEMM=1 keeps the GEMM path (A/B, tests)
+static size_t se_fused_lds(int mcp_max, int se_max) {
+    return (size_t)(((mcp_max + 3) & ~3) + ((se_max + 3) & ~3) + 256 + SE_CH * (se_max | 1)) * sizeof(float);
+}
+static bool se_fused_ok(int mcp_max, int se_max) {
+    static const char* e = getenv("TFNAS_SE_GEMM");
+    if (e && e[0] == '1') return false;
+    return se_max <= 256 && se_fused_lds(mcp_max, se_max) <= 60 * 1024;
 }
 
 #define SE_FINISH(MODE_)                                                                                 \
@@ -260,6 +441,14 @@ int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, f
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
+    if (se_fused_ok(mcp_max, se_max)) {
+        const size_t shm = se_fused_lds(mcp_max, se_max);
+        if (d.act == TFNAS_ACT_RELU)
+            hipLaunchKernelGGL((k_se_fused_fwd<TFNAS_ACT_RELU>), dim3(d.N, ng), dim3(256), shm, s, d, pooled, hpre, gate);
+        else
+            hipLaunchKernelGGL((k_se_fused_fwd<TFNAS_ACT_SWISH>), dim3(d.N, ng), dim3(256), shm, s, d, pooled, hpre, gate);
+        return (int)hipGetLastError();
+    }
     SeArgs a = {pooled, gate, hpre, nullptr, nullptr, hpre, scratch, se_ksplit(d, mcp_max, scratch ? scratch_floats : 0)};
     SE_LAUNCH(0, d.N, se_max)
     SE_FINISH(0)
@@ -275,6 +464,16 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
+    if (se_fused_ok(mcp_max, se_max)) {
+        const size_t shm = se_fused_lds(mcp_max, se_max);
+        if (d.act == TFNAS_ACT_RELU)
+            hipLaunchKernelGGL((k_se_fused_bwd<TFNAS_ACT_RELU>), dim3(d.N, ng), dim3(256), shm, s, d, dgate, gate, hpre,
+                               dhpre, dpooled);
+        else
+            hipLaunchKernelGGL((k_se_fused_bwd<TFNAS_ACT_SWISH>), dim3(d.N, ng), dim3(256), shm, s, d, dgate, gate, hpre,
+                               dhpre, dpooled);
+        return (int)hipGetLastError();
+    }
     SeArgs a = {nullptr, gate, hpre, dgate, dhpre, dhpre, scratch, se_ksplit(d, mcp_max, scratch ? scratch_floats : 0)};
     SE_LAUNCH(2, d.N, se_max)
     SE_FINISH(2)
