@@ -68,7 +68,16 @@ def family_algorithmic(fam, B):
             if launches == 1 and backward and ci == 0:
                 continue                                       # pruned: first cell of the alpha-step
             kernels = launches * (2 if (fam.startswith('k_dw_') and launches == 1) else 1)
-            if fam == 'k_expand_fwd':
+            # E-free mode (functions.py policy): stride-2 cells with ic <= 24 in the alpha-step never form E; the
+            # depthwise kernels recompute it from x (2*P*ic*M extra flops) and BN1's statistics are two passes over x
+            efree = launches == 1 and s == 2 and ic <= 24
+            if fam == 'k_expand_fwd' and efree:
+                f, b, kernels = 2.0 * P * ic * ic, 4.0 * (2 * P * ic), 2
+            elif fam == 'k_dw_fwd' and efree:
+                f, b = 2.0 * Po * M * 17.0 + 2.0 * P * ic * M, 4.0 * (P * ic + Po * M)
+            elif fam == 'k_dw_bwd_data' and efree:
+                f, b = 2.0 * P * M * 17.0 / (s * s) + 2.0 * P * ic * M, 4.0 * (2 * Po * M + P * ic + P * M)
+            elif fam == 'k_expand_fwd':
                 f, b = 2.0 * P * ic * M, 4.0 * (P * ic + P * M + M * ic)
             elif fam == 'k_project_fwd':
                 f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + G * Po * oc + M * oc)
