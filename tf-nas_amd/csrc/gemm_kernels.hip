@@ -85,16 +85,21 @@ template <int NT, int ACT>
 __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, int nsplit, float* __restrict__ prp) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int g = blockIdx.z;
+    // nsplit > 1 (under-filled launches: few row tiles, long K): K-split ks of group g adds chunks [cb, ce); split 0
+    // writes Pr, split z > 0 its partial tile to prp[z-1]; k_pr_reduce sums them and takes the BN3 statistics
+    const int g = blockIdx.z / nsplit, ks = blockIdx.z - g * nsplit;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0, w_al = (mc & 3) == 0;
     const float* __restrict__ w = d.g[g].w_proj;
     const int n0 = blockIdx.y * T::BN;
     const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
-    const int nrt = (Po + 127) >> 7, nchunks = (mcp + 15) >> 4;
+    const int nrt = (Po + 127) >> 7, nchunks_all = (mcp + 15) >> 4;
+    const int per = (nchunks_all + nsplit - 1) / nsplit, cb = ks * per;
+    const int nchunks = max(0, min(nchunks_all, cb + per) - cb);
+    float* __restrict__ dst = ks == 0 ? Pr : prp + (size_t)(ks - 1) * d.G * Po * oc;
     const int tid = threadIdx.x;
 
     float2* cst = reinterpret_cast<float2*>(lds + T::LDS_FLOATS);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellD
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
         auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int p = rt * 128 + row, k = c * 16 + kl;
+            const int p = rt * 128 + row, k = (cb + c) * 16 + kl;
             if (p >= Po || k >= mcp) return zero4();
             f32x4 v = ld4(D + (size_t)p * M + off + k);
             const float2 c0 = cst[k], c1 = cst[k + 1], c2 = cst[k + 2], c3 = cst[k + 3];
@@ -122,17 +127,57 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellD
             return v;
         };
         auto fb = [&](int c, int n, int kl) -> f32x4 {
-            const int o = n0 + n, k = c * 16 + kl;
+            const int o = n0 + n, k = (cb + c) * 16 + kl;
             return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, w_al) : zero4();
         };
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
-            if (p < Po && n0 + lc < oc) st4(Pr + ((size_t)g * Po + p) * oc + n0 + lc, v);
+            if (p < Po && n0 + lc < oc) st4(dst + ((size_t)g * Po + p) * oc + n0 + lc, v);
         });
         acc_colstats<NT>(acc, cs, cq);
     }
-    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
+    if (nsplit == 1)
+        flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
+}
+
+// Pr[g][p][:] += sum_z prp[z][g][p][:] and the per-workgroup partial (sum, sumsq) of the finished Pr per (g, column):
+// part[bx][2*(g*oc + o) + {0,1}] (the layout of k_project_fwd's own statistics epilogue).  Flat float4 stream; a
+// thread's elements are `stride` float4 apart with stride a multiple of oc/4, so its column quad never changes.
+__global__ __launch_bounds__(256) void k_pr_reduce(float* __restrict__ Pr, const float* __restrict__ prp, int nz, int G,
+                                                   int Po, int oc, int rps, float* __restrict__ part) {
+    __shared__ f32x4 rs[256], rq[256];
+    const int tid = threadIdx.x, ocq = oc >> 2, stride = (256 / ocq) * ocq;
+    const int g = blockIdx.y;
+    const int r0 = blockIdx.x * rps, r1 = min(Po, r0 + rps);
+    const size_t base = ((size_t)g * Po + r0) * ocq, zs = (size_t)G * Po * ocq;
+    f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(Pr) + base;
+    const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(prp) + base;
+    const int n4 = (r1 - r0) * ocq;
+    f32x4 s = zero4(), q = zero4();
+    if (tid < stride) {
+        for (int i = tid; i < n4; i += stride) {
+            f32x4 v = p4[i];
+            for (int z = 0; z < nz; ++z) v += z4[(size_t)z * zs + i];
+            p4[i] = v;
+            s += v;
+            q += v * v;
+        }
+    }
+    rs[tid] = s;
+    rq[tid] = q;
+    __syncthreads();
+    for (int c = tid; c < oc; c += 256) {
+        const int cq = c >> 2, comp = c & 3;
+        float ts = 0.f, tq = 0.f;
+        for (int k = cq; k < stride; k += ocq) {
+            ts += rs[k][comp];
+            tq += rq[k][comp];
+        }
+        float* row = part + (size_t)blockIdx.x * 2 * G * oc + 2 * ((size_t)g * oc + c);
+        row[0] = ts;
+        row[1] = tq;
+    }
 }
 
 // ---------------------------------------------------------------------------- BN3-backward operand
@@ -622,10 +667,40 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int tiles = cdiv(d.oc, 16 * nt);
     const int ncols2 = 2 * d.G * d.oc;
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt)), tiles, d.G);
+    const int Po = d.N * d.Ho * d.Wo, nrt = cdiv(Po, 128);
+    // K-split for under-filled launches (sampled mode on the 14x14 / 7x7 cells: 150-400 workgroups walking 30-72
+    // K-chunks back to back at ~2 us per chunk -- one workgroup per CU cannot hide the load latency)
+    int nsplit = 1;
+    const int wgs = nrt * tiles * d.G, kch = cdiv(mcp_max, 16);
+    static const char* nosplit = getenv("TFNAS_PROJECT_NOSPLIT");
+    if (wgs < 512 && kch >= 16 && (d.oc & 3) == 0 && d.oc <= 1024 && !(nosplit && nosplit[0] == '1')) {
+        nsplit = cdiv(1024, wgs);
+        if (nsplit > 4) nsplit = 4;
+        if (nsplit > kch / 8) nsplit = kch / 8;
+        const size_t per = (size_t)d.G * Po * d.oc, rows2 = 256 * (size_t)ncols2;
+        while (nsplit > 1 && (nsplit - 1) * per + rows2 > TFNAS_PART_FLOATS) --nsplit;
+    }
+    if (nsplit > 1) {
+        float* prp = part;
+        float* part2 = part + (size_t)(nsplit - 1) * d.G * Po * d.oc;
+        dim3 grid(nrt, tiles, d.G * nsplit);
+        DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
+            const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
+            hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp);
+        }))
+        int gx2 = cdiv(Po, 64);
+        if (gx2 > 256) gx2 = 256;
+        const int rps = cdiv(Po, gx2);
+        gx2 = cdiv(Po, rps);
+        hipLaunchKernelGGL(k_pr_reduce, dim3(gx2, d.G), dim3(256), 0, s, Pr, prp, nsplit - 1, d.G, Po, d.oc, rps, part2);
+        _prof.stop();
+        return launch_reduce_rows(part2, gx2, ncols2, (size_t)ncols2, stats3, nullptr, s);
+    }
+    dim3 grid(row_blocks(Po, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt)), tiles, d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part);
+        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, 1,
+                           (float*)nullptr);
     }))
     _prof.stop();
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
