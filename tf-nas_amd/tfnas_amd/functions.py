@@ -317,6 +317,7 @@ class SinkFn(torch.autograd.Function):
                                         ptr(bw), _stream()), 'tfnas_sink_fwd')
         ctx.save_for_backward(bw, cl, *rh)
         ctx.K = K
+        ctx.set_materialize_grads(False)      # sampled mode never uses out_lat: no zero-filled gradient for it
         return out.permute(0, 3, 1, 2), out_lat
 
     @staticmethod

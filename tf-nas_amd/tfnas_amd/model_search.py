@@ -286,8 +286,10 @@ class Network(nn.Module):
             if any(c.T != T for c in cells):
                 raise ValueError('all MixedOPs must share one temperature (Network.set_temperature)')
             W, CL = ArchFn.apply(exp_noise.to(dev), torch.stack(lats), T, *[c.log_alphas for c in cells])
-            for i, c in enumerate(cells):
-                c._pre = (W[i], CL[i])
+            # unbind, not W[i]: 18 selects cost 18 zero-filled [18, 8] buffers + 18 slice copies + 17 adds in backward
+            # (on the alpha-step's single dependency chain); unbind's backward is one stack
+            for c, w_c, cl_c in zip(cells, W.unbind(0), CL.unbind(0)):
+                c._pre = (w_c, cl_c)
             return
         if mode in _SAMPLE_MODES:
             if pos is not None:                       # positions already chosen (host-side sampling of search.w_step)
