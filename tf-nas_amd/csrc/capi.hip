@@ -232,8 +232,8 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));
     if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, side_fork(sc, 2, s)));
-    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, x, stats1, dEh, red1, part, s));   // depthwise dgrad + BN1 bwd sums
-    TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
+    // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
+    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, x, stats1, dEh, red1, part, s, cb1));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
     if (dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`

@@ -656,7 +656,7 @@ static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const flo
 static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
                        const double* red2, const float* E, const float* x, const double* stats1, float* dEh, double* red1,
-                       float* part, hipStream_t s) {
+                       float* part, hipStream_t s, float* cb1) {
     const bool ef = E == nullptr;
     if (ef && !efree_ic_ok(d.ic)) return TFNAS_EINVAL;
     const int kq = ef ? d.ic / 4 : 0;
@@ -677,6 +677,7 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
                                red2, E, x, stats1, dEh, part, gm);
         }))
     }
+    if (cb1) return launch_reduce_bn1(d, part, gx, stats1, red1, cb1, s);
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 

@@ -540,6 +540,63 @@ __global__ __launch_bounds__(256) void k_reduce_rows_wide(const float* __restric
     }
 }
 
+// BN1-backward partials -> red1 AND the cb1 table in one launch (what k_reduce_rows + k_bn1_consts did in two):
+// columns (2c, 2c+1) = (T1, T2) of channel c;  cb1[c] = (mean1, rstd1, T1/P, T2/P), zeros for pad channels.
+__global__ __launch_bounds__(256) void k_reduce_bn1(TfnasCellDesc d, const float* __restrict__ part, int nb,
+                                                    const double* __restrict__ stats1, double* __restrict__ red1,
+                                                    float* __restrict__ cb1) {
+    constexpr int CL = 8, RL = 32;
+    __shared__ double buf[RL][CL + 1];
+    __shared__ double tot[CL];
+    const int tid = threadIdx.x, cl = tid % CL, rl = tid / CL;
+    const int ncols = 2 * d.M, c = blockIdx.x * CL + cl;
+    const size_t stride = (size_t)ncols;
+    double s = 0.0;
+    if (c < ncols) {
+        for (int b = rl; b < nb; b += 16 * RL) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (b + RL * u < nb) ? part[(size_t)(b + RL * u) * stride + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+        }
+    }
+    buf[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) t += buf[r][cl];
+        tot[cl] = t;
+        if (c < ncols) red1[c] = t;
+    }
+    __syncthreads();
+    if (tid < CL / 2) {
+        const int ch = blockIdx.x * (CL / 2) + tid;
+        if (ch < d.M) {
+            const double inv = 1.0 / ((double)d.N * d.H * d.W);
+            const float2 m = bn_consts(stats1 + 2 * (size_t)ch, inv, d.eps);
+            f32x4 t;
+            t.x = m.x;
+            t.y = m.y;
+            t.z = (float)(tot[2 * tid] * inv);
+            t.w = (float)(tot[2 * tid + 1] * inv);
+            bool is_pad = true;
+            for (int g = 0; g < d.G; ++g)
+                if (ch >= d.g[g].off && ch < d.g[g].off + d.g[g].mc) is_pad = false;
+            if (is_pad) t = zero4();
+            reinterpret_cast<f32x4*>(cb1)[ch] = t;
+        }
+    }
+}
+
+int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const double* stats1, double* red1, float* cb1,
+                      hipStream_t s) {
+    ProfScope _prof(TK_REDUCE_ROWS, s);
+    hipLaunchKernelGGL(k_reduce_bn1, dim3(cdiv(2 * d.M, 8)), dim3(256), 0, s, d, part, nb, stats1, red1, cb1);
+    return (int)hipGetLastError();
+}
+
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
