@@ -64,7 +64,7 @@ typedef struct TfnasGroup {
     int32_t k;        /* depthwise kernel size: 3 or 5                      [in]  */
     int32_t se;       /* squeeze-excite width, 0 = no SE                    [in]  */
     int32_t mcp;      /* mc rounded up to a multiple of 4                   [plan] */
-    int32_t off;      /* first column of this group in the [.][M] tensors   [plan] */
+    int32_t off;      /* first column of this group in the [.][M] tensors (multiple of 32) [plan] */
     int32_t se_off;   /* first column in the [N][SE] hidden tensors         [plan] */
     int32_t pad0, pad1;
     const float *w_expand, *w_dw, *w_proj, *w_se_r, *b_se_r, *w_se_e, *b_se_e;
@@ -80,7 +80,7 @@ typedef struct TfnasCellDesc {
     int32_t G;                /* number of groups, 1..8                             [in] */
     int32_t need_wgrad;       /* backward also produces weight gradients            [in] */
     int32_t Ho, Wo;           /* output height / width                              [plan] */
-    int32_t M;                /* sum of mcp over groups                             [plan] */
+    int32_t M;                /* row length of the [.][M] tensors: groups padded to 32-float (128 B) boundaries [plan] */
     int32_t SE;               /* sum of se over groups                              [plan] */
     float eps;                /* BatchNorm eps (1e-5)                               [in] */
     int32_t mode;             /* TFNAS_MODE_CELL / _STEM / _HEAD                    [in] */

@@ -57,12 +57,12 @@ def test_plan_and_workspace_geometry(lib):
     d = _desc()
     assert lib.tfnas_cell_plan(C.byref(d)) == 0
     assert (d.Ho, d.Wo) == (9, 11)
-    assert [d.g[0].mcp, d.g[1].mcp, d.g[0].off, d.g[1].off, d.M, d.SE] == [32, 56, 0, 32, 88, 24]
+    assert [d.g[0].mcp, d.g[1].mcp, d.g[0].off, d.g[1].off, d.M, d.SE] == [32, 56, 0, 32, 96, 24]   # groups / rows on 128-B lines
     ws = _lib.TfnasCellWs()
     assert lib.tfnas_cell_ws(C.byref(d), C.byref(ws)) == 0
     P = 2 * 9 * 11
-    assert (ws.E, ws.D, ws.Pr, ws.out, ws.dx) == (P * 88, P * 88, 2 * P * 24, P * 24, P * 24)
-    assert ws.stats == 4 * 88 + 2 * 2 * 24 and ws.off_stats3 == 4 * 88
+    assert (ws.E, ws.D, ws.Pr, ws.out, ws.dx) == (P * 96, P * 96, 2 * P * 24, P * 24, P * 24)
+    assert ws.stats == 4 * 96 + 2 * 2 * 24 and ws.off_stats3 == 4 * 96
     d2 = _desc(H=112, W=112, ic=16, oc=24, stride=2)
     assert lib.tfnas_cell_plan(C.byref(d2)) == 0 and (d2.Ho, d2.Wo) == (56, 56)
     d3 = _desc(H=9, W=13, ic=24, oc=40, stride=2)

@@ -96,10 +96,24 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         TfnasGroup& gr = d->g[g];
         if (gr.mc < 1 || (gr.k != 3 && gr.k != 5) || gr.se < 0) return TFNAS_EINVAL;
         gr.mcp = (gr.mc + 3) & ~3;
+        // every group starts on a 128-byte line of the [pixels][M] rows (and M is a multiple of 32 floats, so every row
+        // does too): the 32-channel segments the depthwise kernels move and the 64-column GEMM tiles are then whole
+        // lines.  Packed groups (72 / 144 / 120 / 336 floats wide) left most of them 32..96 bytes off, i.e. partial-line
+        // writes and two lines fetched per segment.  The pad columns are never read or written.
+        static const char* noalign = getenv("TFNAS_NO_ALIGN");
+        const bool al = !(noalign && noalign[0] == '1');
+        if (al) off = (off + 31) & ~31;
         gr.off = off;
         gr.se_off = se_off;
         off += gr.mcp;
         se_off += gr.se;
+    }
+    {
+        static const char* noalign = getenv("TFNAS_NO_ALIGN");
+        if (!(noalign && noalign[0] == '1')) {
+            off = (off + 31) & ~31;
+            if ((off & 511) == 0) off += 32;          // no power-of-two-ish row stride (HBM channel aliasing)
+        }
     }
     d->M = off;
     d->SE = se_off;
