@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 4) void k_expand_fwd(TfnasCellDesc d, const fl
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
-            if (p < P && n0 + lc < mcp) st4(E + (size_t)p * M + off + n0 + lc, v);
+            if (p < P && n0 + lc < mcp) st4_nt(E + (size_t)p * M + off + n0 + lc, v);
         });
         acc_colstats<NT>(acc, cs, cq);
     }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_dgrad(TfnasCel
         gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
-            if (p < Po && n0 + lc < mcp) st4(dZ + (size_t)p * M + off + n0 + lc, v);
+            if (p < Po && n0 + lc < mcp) st4_nt(dZ + (size_t)p * M + off + n0 + lc, v);
         });
     }
 }

@@ -57,6 +57,16 @@ __device__ __forceinline__ float2 bn_consts(const double* st, double inv_cnt, fl
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// non-temporal variants for the once-through [pixels][M] streams (see dw_stream.inc)
+#ifdef TFNAS_NO_NT
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) { return ld4(p); }
+__device__ __forceinline__ void st4_nt(float* p, f32x4 v) { st4(p, v); }
+#else
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+__device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+#endif
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x4 splat4(float a) { f32x4 z = {a, a, a, a}; return z; }
 
