@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT, bool STEM>
-__global__ __launch_bounds__(256, 4) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
                                                     float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
@@ -644,17 +644,47 @@ static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30, int slo
 }
 static inline int gemm_slots(int nt) { return 256 * (nt >= 5 ? 3 : 4); }
 
+// Column-tile width of the GEMMs whose N extent is the mid channels of EVERY group (tiles cannot straddle groups): the
+// candidate that pads the group widths least (72 | 144 -> 5 x 16: 960 columns for 864, where 4 x 16 needs 1280 and
+// 20 tiles instead of 12; 336 | 672 -> 7 x 16 exactly), the wider one on ties.  TFNAS_NT_GROUPS=0: always 4.
+static int pick_nt_groups(const TfnasCellDesc& d) {
+    static const char* e = getenv("TFNAS_NT_GROUPS");
+    if (e && e[0] == '0') return 4;
+    // only for cells with narrow groups (the HBM-bound 56x56 / 28x28 cells): on the matrix-bound later cells the 64-wide
+    // tile at 4 waves/SIMD beats the 80- / 112-wide ones at 3 even when those fit exactly (measured)
+    int min_mcp = 1 << 30;
+    for (int g = 0; g < d.G; ++g) min_mcp = d.g[g].mcp < min_mcp ? d.g[g].mcp : min_mcp;
+    if (min_mcp >= 200) return 4;
+    static const int cands[] = {4, 5, 7};
+    int best = 4;
+    long best_pad = -1;
+    for (int i = 0; i < 3; ++i) {
+        long pad = 0;
+        for (int g = 0; g < d.G; ++g) pad += (long)cdiv(d.g[g].mcp, 16 * cands[i]) * 16 * cands[i];
+        if (best_pad < 0 || pad < best_pad || (pad == best_pad && cands[i] > best)) {
+            best_pad = pad;
+            best = cands[i];
+        }
+    }
+    return best;
+}
+
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
                       hipStream_t s) {
     ProfScope _prof(TK_EXPAND_FWD, s);
-    constexpr int NT = 4;
+    const int nt = d.mode == TFNAS_MODE_STEM ? 4 : pick_nt_groups(d);
     int tiles = 0;
-    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M)), tiles);
-    if (d.mode == TFNAS_MODE_STEM)
-        hipLaunchKernelGGL((k_expand_fwd<NT, true>), grid, dim3(256), 0, s, d, x, E, part);
-    else
-        hipLaunchKernelGGL((k_expand_fwd<NT, false>), grid, dim3(256), 0, s, d, x, E, part);
+    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt)), tiles);
+    if (d.mode == TFNAS_MODE_STEM) {
+        hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part);
+    } else {
+        switch (nt) {
+            case 5: hipLaunchKernelGGL((k_expand_fwd<5, false>), grid, dim3(256), 0, s, d, x, E, part); break;
+            case 7: hipLaunchKernelGGL((k_expand_fwd<7, false>), grid, dim3(256), 0, s, d, x, E, part); break;
+            default: hipLaunchKernelGGL((k_expand_fwd<4, false>), grid, dim3(256), 0, s, d, x, E, part); break;
+        }
+    }
     _prof.stop();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
@@ -709,12 +739,14 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
                          const double* red3, const float* wmix, float* dZ, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_DGRAD, s);
-    constexpr int NT = 4;
+    const int nt = pick_nt_groups(d);
     int tiles = 0;
-    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * NT);
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(NT)), tiles);
-    const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
-    hipLaunchKernelGGL(k_project_dgrad<NT>, grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
+    for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(nt)), tiles);
+    DISPATCH_NT(nt, {
+        const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
+        hipLaunchKernelGGL(k_project_dgrad<NT>, grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
+    })
     return (int)hipGetLastError();
 }
 
