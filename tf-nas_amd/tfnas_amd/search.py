@@ -11,6 +11,7 @@ is needed), BatchNorm statistics are per rank, and gradients are averaged with O
 weight grads of the sampled paths in the w-step (~35 MB, RCCL over xGMI), the 162 arch scalars in the alpha-step.
 Gradient clipping runs after the reduction, on the averaged gradients (train_search.py:383-384,416-417).
 """
+import os
 import random
 
 import numpy as np
@@ -24,14 +25,18 @@ from .functions import arch_project
 
 def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-4, a_betas=(0.5, 0.999)):
     """train_search.py:197-206."""
-    opt_w = torch.optim.SGD(model.weight_parameters(), lr=w_lr, momentum=w_mom, weight_decay=w_wd)
+    params = model.weight_parameters()
+    # one fused kernel per chunk of tensors instead of three multi-tensor passes (weight decay, momentum, update)
+    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get('TFNAS_FUSED_OPT', '1') != '0'
+    opt_w = torch.optim.SGD(params, lr=w_lr, momentum=w_mom, weight_decay=w_wd, **({'fused': True} if fused else {}))
     # Zero momentum buffers up front.  torch's multi-tensor SGD falls back to two tiny per-tensor kernels for EVERY
     # parameter of a step as soon as one of them has no buffer yet -- which, with a freshly sampled sub-network per
     # step, is the normal case for the first few hundred steps.  buf = 0*momentum + grad equals the first-step
     # buf = clone(grad) bit for bit (dampening = 0), so the trajectory is unchanged.
     for p in opt_w.param_groups[0]['params']:
         opt_w.state[p]['momentum_buffer'] = torch.zeros_like(p)
-    opt_a = torch.optim.Adam(model.arch_parameters(), lr=a_lr, betas=a_betas, weight_decay=a_wd)
+    opt_a = torch.optim.Adam(model.arch_parameters(), lr=a_lr, betas=a_betas, weight_decay=a_wd,
+                             **({'fused': True} if fused else {}))
     return opt_w, opt_a
 
 
