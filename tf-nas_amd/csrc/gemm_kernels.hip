@@ -672,12 +672,14 @@ static int pick_nt_groups(const TfnasCellDesc& d) {
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
                       hipStream_t s) {
     ProfScope _prof(TK_EXPAND_FWD, s);
-    const int nt = d.mode == TFNAS_MODE_STEM ? 4 : pick_nt_groups(d);
+    // stem: 32 output channels -> 32-wide tiles (a 64-wide tile would be half empty)
+    const int nt = d.mode == TFNAS_MODE_STEM ? (d.g[0].mcp <= 32 ? 2 : 4) : pick_nt_groups(d);
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt)), tiles);
     if (d.mode == TFNAS_MODE_STEM) {
-        hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part);
+        if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true>), grid, dim3(256), 0, s, d, x, E, part);
+        else hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part);
     } else {
         switch (nt) {
             case 5: hipLaunchKernelGGL((k_expand_fwd<5, false>), grid, dim3(256), 0, s, d, x, E, part); break;
