@@ -242,10 +242,15 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     else TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
     // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, dEh, (size_t)d.N * d.H * d.W * d.M, s));
-    if (d.need_wgrad) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, side_fork(sc, 1, s)));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));
-    if (d.need_wgrad) TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, side_fork(sc, 2, s)));
+    if (d.need_wgrad) {
+        // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
+        // host-bound w-step; cells without SE launch nothing for it)
+        hipStream_t sw = side_fork(sc, 2, s);
+        if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
+        TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, sw));
+    }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
     TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, x, stats1, dEh, red1, part, s, cb1));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
