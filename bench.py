@@ -11,7 +11,15 @@ whole job (all ranks), inputs already resident in HBM, optimizer steps / clippin
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant HIP kernel family of the timed region, timed live with HIP events on the launch
-                stream (tfnas_prof_* hooks), vs its algorithmic flops / HBM bytes.
+                stream (tfnas_prof_* hooks), vs its algorithmic flops / HBM bytes (DESIGN.md section 5);
+                roofline.pair = the whole iteration pair against SURVEY.md 8(d)'s algorithmic floor
+                (t_lower_ms, achieved = t_lower / t, hbm_fraction vs F0, mfma_fraction of the 1x1 flops).
+  w_step_ms / a_step_ms   GPU time of the two kinds of step (HIP events on the launch stream, a few pairs after
+                the timed region).
+  dropin_images_per_s     the same iteration pair written exactly like the reference's train_w_arch body
+                (train_search.py:370-426: sequential model(x, True, 'gumbel') / model(x, True, 'random') forwards,
+                sampling on the device, torch's clip_grad_norm_ / per-parameter projection loop) -- what a user gets
+                from the two-line import swap of INTEGRATION.md without adopting tfnas_amd.search.
   cpu_baseline  the CPU oracle (plain PyTorch restatement, proven equal to the reference) timed on this host's
                 cores on a bounded sample of the same loop at the reference's batch 32 (N=1, rank 0 only).
 """
@@ -58,7 +66,7 @@ def family_algorithmic(fam, B):
     from tfnas_amd import geometry as g
     fl = by = 0.0
     n = 0
-    backward = fam in ('k_project_dgrad', 'k_expand_dgrad', 'k_dw_bwd_data', 'k_bn2_bwd')
+    backward = fam in ('k_project_dgrad', 'k_expand_dgrad', 'k_dw_bwd_data', 'k_se_pool<bwd>')
     for ci, (name, N, H, W, ic, oc, s, mids) in enumerate(cell_table(B)):
         P, Po = N * H * W, N * ((H - 1) // s + 1) * ((W - 1) // s + 1)
         Msoft = sum(mids)
@@ -91,8 +99,8 @@ def family_algorithmic(fam, B):
             elif fam == 'k_dw_bwd_data':
                 kk = 17.0
                 f, b = 2.0 * P * M * kk / (s * s), 4.0 * (2 * Po * M + 2 * P * M)
-            elif fam == 'k_bn2_bwd':
-                f, b = 8.0 * Po * M, 4.0 * (3 * Po * M)
+            elif fam == 'k_se_pool<bwd>':                      # k_bn2_pool: ONE pass over (dZ, D); k_bn2_finish is tiny
+                f, b = 8.0 * Po * M, 4.0 * (2 * Po * M)
             elif fam in ('k_project_wgrad', 'k_expand_wgrad', 'k_dw_wgrad'):
                 if launches == 1:
                     continue                                   # no weight grads in the alpha-step
@@ -108,6 +116,69 @@ def family_algorithmic(fam, B):
             by += b * launches
             n += kernels
     return fl, by, n
+
+
+def pair_algorithmic(B, elt=4):
+    """algorithmic bytes F0 and flops of ONE iteration pair (w-step, alpha-step, w-step) at batch B.
+    alpha-step, cell c: (3X + 2Y)*s + 2*sum_i P_i*s;  w-step: sum over the two sampled paths of (3X + 2Y)*s + P*s + 2*P*4
+    (expected value over a uniform candidate choice).  Flops: fwd + input-grad (alpha-step, 2x fwd of all 8 candidates),
+    fwd + dX + dW (w-step, 3x fwd of 2 of the 8).  Returns dict(bytes, flops_1x1, flops_other)."""
+    f0_a = f0_w = mac_pw = mac_other = 0.0
+    for name, N, H, W, ic, oc, s, mids in cell_table(B):
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        X, Y = float(N) * ic * H * W, float(N) * oc * Ho * Wo
+        params, pw, other = [], 0.0, 0.0
+        for i, mc in enumerate(mids):
+            k = 3 if i in (0, 1, 4, 5) else 5
+            se = 0 if i < 4 else ic * (1 if i % 2 == 0 else 2)
+            params.append(mc * ic + mc * k * k + oc * mc + (2 * se * mc + se + mc if se else 0))
+            pw += float(N) * (H * W * ic * mc + Ho * Wo * mc * oc)
+            other += float(N) * (Ho * Wo * mc * k * k + (2 * se * mc if se else 0))
+        f0_a += (3 * X + 2 * Y) * elt + 2 * sum(params) * elt
+        pmean = sum(params) / 8.0
+        f0_w += 2 * ((3 * X + 2 * Y) * elt + pmean * elt + 2 * pmean * 4)
+        mac_pw += pw
+        mac_other += other
+    # alpha-step = 2 x fwd(all 8); each w-step = 3 x fwd x 2 paths / 8 candidates
+    mult = 2.0 + 2 * 3.0 * 2.0 / 8.0
+    return dict(bytes=f0_a + 2 * f0_w, flops_1x1=2.0 * mac_pw * mult, flops_other=2.0 * mac_other * mult,
+                bytes_alpha=f0_a, bytes_w=f0_w)
+
+
+def dropin_pair(model, opt_w, opt_a, bw, ba, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0):
+    """Two iterations of the reference's train_w_arch body (train_search.py:370-426) written the way the reference writes
+    them, against the drop-in model: requires_grad toggling over named_parameters, two sequential sampled forwards with
+    device-side sampling, torch clip + optimizer, per-parameter log_softmax projection."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    for step, (x_w, target_w) in enumerate(bw):
+        for p in model.weight_parameters():
+            p.requires_grad = True
+        for p in model.arch_parameters():
+            p.requires_grad = False
+        logits_g, _ = model(x_w, sampling=True, mode='gumbel')
+        loss_g = F.cross_entropy(logits_g, target_w)
+        logits_r, _ = model(x_w, sampling=True, mode='random')
+        loss_r = F.cross_entropy(logits_r, target_w)
+        loss_w = loss_g + loss_r
+        opt_w.zero_grad()
+        loss_w.backward()
+        nn.utils.clip_grad_norm_(model.weight_parameters(), grad_clip)
+        opt_w.step()
+        if step % 2 == 0:
+            x_a, target_a = ba
+            for p in model.weight_parameters():
+                p.requires_grad = False
+            for p in model.arch_parameters():
+                p.requires_grad = True
+            logits, lat = model(x_a, sampling=False)
+            loss = F.cross_entropy(logits, target_a) + torch.abs(lat / target_lat - 1.) * lambda_lat
+            opt_a.zero_grad()
+            loss.backward()
+            nn.utils.clip_grad_norm_(model.arch_parameters(), grad_clip)
+            opt_a.step()
+            for p in model.arch_parameters():
+                p.data = F.log_softmax(p.detach().data, dim=-1)
 
 
 def run_gpu(args):
@@ -185,6 +256,42 @@ def run_gpu(args):
     dom = collect()[dominant]
     lib.tfnas_prof_enable(0)
 
+    # ---- after the timed region: GPU time of the w-step and the alpha-step (HIP events on the launch stream; the
+    # w-step's side streams fork from and join it) over a few more pairs
+    nsplit = max(1, min(10, args.steps))
+    evs = []
+    for i in range(nsplit):
+        j = args.warmup + 1 + args.steps + i
+        bw = (train[(2 * j) % len(train)], train[(2 * j + 1) % len(train)])
+        ba = val[j % len(val)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        search.w_step(state, bw[0][0], bw[0][1], opt_w, 5.0, noise.exp(dev), noise.rand_pos())
+        e[1].record()
+        search.a_step(state, ba[0], ba[1], opt_a, 15.0, 0.1, 5.0, noise.exp(dev))
+        e[2].record()
+        search.w_step(state, bw[1][0], bw[1][1], opt_w, 5.0, noise.exp(dev), noise.rand_pos())
+        e[3].record()
+        evs.append(e)
+    torch.cuda.synchronize()
+    w_ms = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs) / (2 * nsplit)
+    a_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / nsplit
+
+    # ---- the reference-style loop on the drop-in model (world 1 only: it has no gradient all-reduce)
+    dropin = None
+    if world == 1 and not args.no_dropin:
+        import random
+        random.seed(2)
+        model.reset_switches()
+        nd, wd_ = max(1, min(10, args.steps)), 2
+        for i in range(wd_ + nd):
+            if i == wd_:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            dropin_pair(model, opt_w, opt_a, (train[(2 * i) % len(train)], train[(2 * i + 1) % len(train)]), val[i % len(val)])
+        torch.cuda.synchronize()
+        dropin = 2.0 * B * nd / (time.perf_counter() - t0)
+
     result = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -202,9 +309,26 @@ def run_gpu(args):
             else:
                 roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                             frac=round(gbs / PEAK_HBM_GBS, 4))
+            if roof['frac'] > 1.0:
+                raise SystemExit('bench.py: byte/flop model of %s gives frac %.2f > 1 -- the model is wrong' % (dominant, roof['frac']))
             roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 4), launches_timed=dom[0],
                         alg_flops_per_launch=fl / nl, alg_bytes_per_launch=by / nl, traffic=None,
                         share_of_step=round(dom[1] / args.steps / ms_per_step, 3))
+        # whole pair against SURVEY 8(d)'s algorithmic floor: F0 bytes at 8 TB/s, 1x1 flops on the fp32 MFMA peak,
+        # depthwise + SE flops on the fp32 vector peak (same 157.3 TF/s)
+        pa = pair_algorithmic(B)
+        t = ms_per_step * 1e-3
+        t_hbm, t_mfma, t_valu = pa['bytes'] / (PEAK_HBM_GBS * 1e9), pa['flops_1x1'] / (PEAK_FP32_MFMA_TF * 1e12), \
+            pa['flops_other'] / (PEAK_FP32_MFMA_TF * 1e12)
+        t_lower = max(t_hbm, t_mfma, t_valu)
+        pair_roof = dict(t_lower_ms=round(t_lower * 1e3, 3), achieved=round(t_lower / t, 4),
+                         hbm_fraction=round(t_hbm / t, 4), mfma_fraction=round(t_mfma / t, 4),
+                         f0_bytes=pa['bytes'], flops_1x1=pa['flops_1x1'], flops_dw_se=pa['flops_other'],
+                         note='SURVEY.md 8(d): t_lower = max(F0/8 TB/s, 1x1 flops/157.3 TF/s fp32 MFMA, dw+SE flops/157.3 TF/s)')
+        if roof is not None:
+            roof['pair'] = pair_roof
+        else:
+            roof = dict(pair=pair_roof)
         result = dict(metric='supernet search images/sec (w-step + alpha-step)', value=round(value, 2), unit='images/s',
                       n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3),
                       higher_is_better=True, scaling='weak', vs_baseline=None, dtype='fp32', data='synthetic',
@@ -213,7 +337,9 @@ def run_gpu(args):
                                            'initial widths, T=5, target_lat=15 (BASELINE configs[1] geometry, fp32)',
                                   batch_per_gpu=B, global_batch=B * world, train_images_per_step=2 * B * world,
                                   parallelism='dp%d' % world),
-                      roofline=roof,
+                      roofline=roof, w_step_ms=round(w_ms, 3), a_step_ms=round(a_ms, 3),
+                      all_images_per_s=round(3.0 * B * world * args.steps / dt, 2),
+                      dropin_images_per_s=None if dropin is None else round(dropin, 2),
                       kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
                                           if v[0]})
     if dist.is_initialized():
@@ -221,10 +347,15 @@ def run_gpu(args):
     return result
 
 
-def run_cpu_baseline(seconds_budget=25.0, B=32):
-    """Time the CPU oracle on a bounded sample of the same loop at the reference's batch 32.
-    The thread count is probed (16/32/64/all cores on a short forward+backward) because oneDNN scales badly past
-    one socket on big hosts (256 hardware threads made one iteration take minutes on the GPU box)."""
+def run_cpu_baseline(B=32):
+    """Time the CPU oracle on a bounded sample of the same loop at the reference's batch 32 (SURVEY 8(d) "CPU baseline beside it").
+    Three legs, all reported:
+      best     thread count probed on a short step (8/16/32/64): oneDNN scales badly past one socket on big hosts; this
+               is the headline `value`: 3 warm-up + 10 timed iteration pairs;
+      t8       pinned to 8 threads (comparable with the 8-vCPU build container, SURVEY 6: ~8.5 img/s): 1 warm-up + 3 pairs;
+      allcores torch.set_num_threads(os.cpu_count()): wall-clock capped at 40 s (256 threads made one pair take minutes
+               on the GPU box in round 1) -- reports whatever completed.
+    Sized so the whole leg stays around two minutes."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import tfnas_oracle as orc
     from tfnas_amd.latency import load_lat_lookup
@@ -243,6 +374,26 @@ def run_cpu_baseline(seconds_budget=25.0, B=32):
         t0 = time.perf_counter()
         orc.w_step(model, xs[0], ys[0], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos(), bi_sampling=False)
         return time.perf_counter() - t0
+
+    def pair():
+        orc.w_step(model, xs[0], ys[0], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
+        orc.a_step(model, xs[1], ys[1], opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
+        orc.w_step(model, xs[2], ys[2], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
+
+    def leg(threads, warm, n, budget):
+        torch.set_num_threads(threads)
+        t_start = time.perf_counter()
+        for _ in range(warm):
+            pair()
+            if time.perf_counter() - t_start > budget:
+                return dict(threads=threads, pairs=0, value=None, note='warm-up exceeded %.0f s' % budget)
+        done, t0 = 0, time.perf_counter()
+        while done < n and (done == 0 or time.perf_counter() - t_start < budget):
+            pair()
+            done += 1
+        dt = (time.perf_counter() - t0) / done
+        return dict(threads=threads, pairs=done, warmup=warm, value=round(2 * B / dt, 3), ms_per_pair=round(dt * 1e3, 1))
+
     best_t, threads = None, 1
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
@@ -250,28 +401,17 @@ def run_cpu_baseline(seconds_budget=25.0, B=32):
         t = probe()
         if best_t is None or t < best_t:
             best_t, threads = t, nt
-    torch.set_num_threads(threads)
-
-    def pair():
-        orc.w_step(model, xs[0], ys[0], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
-        orc.a_step(model, xs[1], ys[1], opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
-        orc.w_step(model, xs[2], ys[2], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
-    t0 = time.perf_counter()
-    pair()                                   # warm-up (oneDNN primitive creation)
-    warm = time.perf_counter() - t0
-    n, t0 = 0, time.perf_counter()
-    while n < 3 and (n == 0 or (time.perf_counter() - t0) + warm < seconds_budget):
-        pair()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return dict(value=round(2 * B / dt, 3), unit='images/s', cores=threads, kind='port',
-                sample='%d iteration pair(s) (w-step, alpha-step, w-step) of oracle/tfnas_oracle.py at batch %d fp32 '
-                       'after 1 warm-up pair; torch %s, %d threads (best of 8/16/32/64 probed) on a %d-thread host'
-                       % (n, B, torch.__version__, threads, ncpu),
-                ms_per_step=round(dt * 1e3, 1))
+    best = leg(threads, 3, 10, 75.0)
+    t8 = leg(min(8, ncpu), 1, 3, 45.0)
+    allc = leg(ncpu, 1, 3, 40.0) if ncpu not in (threads, 8) else dict(threads=ncpu, note='same as another leg')
+    return dict(value=best['value'], unit='images/s', cores=threads, kind='port',
+                sample='%d iteration pairs (w-step, alpha-step, w-step) of oracle/tfnas_oracle.py at batch %d fp32 after %d '
+                       'warm-up pairs; torch %s, %d threads (best of 8/16/32/64 probed) on a %d-thread host'
+                       % (best['pairs'], B, best.get('warmup', 0), torch.__version__, threads, ncpu),
+                ms_per_step=best.get('ms_per_pair'), threads8=t8, all_cores=allc, host_threads=ncpu)
 
 
-def cpu_baseline_subprocess(timeout=240):
+def cpu_baseline_subprocess(timeout=330):
     """Run the CPU leg in a child process with a hard wall-clock limit so the bench line is always printed."""
     import subprocess
     try:
@@ -306,8 +446,9 @@ def _attach_pmc_traffic(res):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50, help='timed iteration pairs (SURVEY 8(d): >= 50)')
+    ap.add_argument('--warmup', type=int, default=10, help='untimed warm-up pairs (>= 10)')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the reference-style drop-in loop timing')
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step-half (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)

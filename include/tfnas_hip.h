@@ -13,7 +13,9 @@
  *    scratch; sizes come from tfnas_cell_ws();
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *  - return value: 0 ok, <0 invalid argument (TFNAS_E*), >0 a hipError_t;
- *  - no global mutable state; re-entrant per stream.
+ *  - re-entrant per stream.  The only process-global state is a registry of library-owned side streams (one per
+ *    caller stream and device, created on first use by tfnas_mixedop_bwd with need_wgrad; released by
+ *    tfnas_shutdown()) and the opt-in tfnas_prof_* timers; results never depend on either.
  *
  * A "cell" is one MixedOP (18 per network); its G "groups" are the MBConv candidates evaluated in this
  * call: G = 8 in the soft (alpha-step) mode, G = 1 in the sampled (w-step) mode.  All groups' expanded
@@ -117,6 +119,9 @@ typedef struct TfnasCellWs {
 } TfnasCellWs;
 
 int tfnas_abi_version(void);
+
+/* Destroys the library-owned side streams / events (after synchronising them).  Optional; safe to call more than once. */
+int tfnas_shutdown(void);
 
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs. */
 uint64_t tfnas_sizeof(int which);

@@ -355,6 +355,27 @@ def a_step(model, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     return loss_a.detach(), loss_l.detach(), lat.detach(), grads
 
 
+def validate(model, batches, noises):
+    """``validate`` (train_search.py:435-462): no-grad 'gumbel' forward per batch in train mode, reset_switches after
+    each, running averages weighted by batch size.  Returns (top1.avg, top5.avg, objs.avg, [gumbel indices per batch])."""
+    tot = n_all = t1 = t5 = 0.0
+    idxs = []
+    for (x, y), e in zip(batches, noises):
+        with torch.no_grad():
+            logits, _ = model(x, True, 'gumbel', exp_noise=e)
+            loss = F.cross_entropy(logits, y)
+        idxs.append([c.last_idx for c in model.cells()])
+        model.reset_switches()
+        _, pred = logits.topk(5, 1, True, True)
+        hit = pred.t().eq(y.view(1, -1))
+        n = x.size(0)
+        t1 += float(hit[:1].sum()) * 100.0
+        t5 += float(hit[:5].sum()) * 100.0
+        tot += float(loss) * n
+        n_all += n
+    return t1 / n_all, t5 / n_all, tot / n_all, idxs
+
+
 def initial_mc_num_dddict(e3=3, e6=6):
     d = OrderedDict()
     for name, (ics, ocs, ss, act) in STAGE_CFG.items():

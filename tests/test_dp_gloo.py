@@ -42,7 +42,7 @@ def _worker(rank, world, port, outdir):
     xs, ys = X[2 * rank:2 * rank + 2], Y[2 * rank:2 * rank + 2]
     search.w_step(state, xs, ys, opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
     gidx = [c.last_idx for c in model.cells()]
-    _, _, lat, grads = search.a_step(state, xs, ys, opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
+    _, _, lat, grads = search.a_step(state, xs, ys, opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'), return_grads=True)
     torch.save(dict(arch=[p.detach().clone() for p in model.arch_parameters()],
                     wsum=[float(p.detach().double().sum()) for p in model.weight_parameters()],
                     grads=grads, gidx=gidx, lat=float(lat)), os.path.join(outdir, 'r%d.pt' % rank))

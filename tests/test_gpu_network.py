@@ -121,7 +121,8 @@ def test_search_steps_teacher_forced_and_free_running(lut):
                 # strict single-step gate from identical state
                 _sync_state(o, m, oo, mo)
             la_o, ll_o, lat_o, g_o = orc.a_step(o, x, y, oo[1], 15.0, 0.1, 5.0, noise=na)
-            la_m, ll_m, lat_m, g_m = search.a_step(st, x.cuda(), y.cuda(), mo[1], 15.0, 0.1, 5.0, noise=na.cuda())
+            la_m, ll_m, lat_m, g_m = search.a_step(st, x.cuda(), y.cuda(), mo[1], 15.0, 0.1, 5.0, noise=na.cuda(),
+                                                    return_grads=True)
             assert abs(float(lat_o) - float(lat_m)) < 1e-3
             if it == 0:
                 for a, b in zip(g_o, g_m):
@@ -203,7 +204,7 @@ def _pair_with_widths(lut, mc, seed=2, T=5.0):
     return o, m.cuda()
 
 
-@pytest.mark.parametrize('widths', ['e2_e4', 'e4_e8', 'ragged_target15', 'ragged_target10'])
+@pytest.mark.parametrize('widths', ['e2_e4', 'e3_e6', 'e4_e8', 'ragged_target15', 'ragged_target10', 'ragged_target18'])
 def test_width_sweep_matches_oracle(lut, widths):
     """BASELINE configs[3]: expand ratios across the reachable range + ragged widths produced by elasticity scaling
     (fit_mc_num_by_latency), latency lookup executed in the soft forward."""
@@ -213,32 +214,54 @@ def test_width_sweep_matches_oracle(lut, widths):
     from tfnas_amd.latency import get_lookup_latency
     if widths == 'e2_e4':
         mc = g.uniform_mc_num_dddict(2, 4)
+    elif widths == 'e3_e6':
+        mc = g.uniform_mc_num_dddict(3, 6)
     elif widths == 'e4_e8':
         mc = g.uniform_mc_num_dddict(4, 8)
     else:
         base = g.initial_mc_num_dddict()
         mcmax = g.get_mc_num_dddict(g.make_mc_mask_dddict(), is_max=True)
         keys = g.make_lat_lookup_key_dddict()
-        target = 15.0 if widths.endswith('15') else 10.0
+        target = float(widths[-2:])
         mc = base
         for op in (1, 7, 4):                                   # scale three different candidates -> many ragged widths
             arch = OrderedDict((st, OrderedDict((b, op) for b in base[st])) for st in base)
             lat = get_lookup_latency(arch, mc, keys, lut)
             mc, _ = fit_mc_num_by_latency(arch, mc, mcmax, keys, lut, target, list(base.keys()), -1 if lat > target else 1)
-        if target == 15.0:          # (target 10 clips to the floor widths max//2, which are multiples of 4)
+        if target != 10.0:          # (target 10 clips to the floor widths max//2, which are multiples of 4)
             assert any(v % 4 for st in mc.values() for b in st.values() for v in b.values())
     o, m = _pair_with_widths(lut, mc)
     gen = torch.Generator().manual_seed(4)
     x = torch.randn(2, 3, 224, 224, generator=gen)
     noise = torch.empty(18, 8).exponential_(generator=gen)
-    with torch.no_grad():
-        lo, lato = o(x, False, exp_noise=noise)
-        lm, latm = m(x.cuda(), False, exp_noise=noise.cuda())
-        so, _ = o(x, True, 'gumbel', exp_noise=noise)
-        sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    y = torch.randint(0, 100, (2,), generator=gen)
+    for p in o.weight_parameters() + m.weight_parameters():
+        p.requires_grad = False
+    lo, lato = o(x, False, exp_noise=noise)
+    lm, latm = m(x.cuda(), False, exp_noise=noise.cuda())
     assert abs(float(lato) - float(latm)) < 1e-3
     assert torch.allclose(lm.cpu(), lo, atol=1e-3, rtol=1e-3), float((lm.cpu() - lo).abs().max())
+    # backward of the alpha-step loss at these widths (latency lookup in the loop, target = the sweep's target)
+    tl = 15.0 if not widths.startswith('ragged') else float(widths[-2:])
+    (torch.nn.functional.cross_entropy(lo, y) + torch.abs(lato / tl - 1.) * 0.1).backward()
+    (torch.nn.functional.cross_entropy(lm, y.cuda()) + torch.abs(latm / tl - 1.) * 0.1).backward()
+    for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
+        if k.endswith('log_alphas') or k.endswith('betas'):
+            assert torch.allclose(b.grad.cpu(), a.grad, atol=1e-4), (k, float((b.grad.cpu() - a.grad).abs().max()))
+    # a sampled w-step path (weight gradients) at the same widths
+    for p in o.weight_parameters() + m.weight_parameters():
+        p.requires_grad = True
+    so, _ = o(x, True, 'gumbel', exp_noise=noise)
+    sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
     assert torch.allclose(sm.cpu(), so, atol=1e-3, rtol=1e-3)
+    torch.nn.functional.cross_entropy(so, y).backward()
+    torch.nn.functional.cross_entropy(sm, y.cuda()).backward()
+    for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
+        if a.grad is None or k.endswith('log_alphas') or k.endswith('betas'):
+            continue
+        err, ref = float((b.grad.cpu() - a.grad).abs().max()), float(a.grad.abs().max())
+        assert err <= 2e-5 + 2e-3 * ref, (k, err, ref)
+    o.reset_switches(); m.reset_switches()
 
 
 def test_warmup_step_without_arch_matches_oracle(lut):
@@ -257,3 +280,30 @@ def test_warmup_step_without_arch_matches_oracle(lut):
     assert all(all(c.switches) for c in m.cells())
     for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
         assert torch.allclose(b.detach().cpu(), a.detach(), atol=1e-4, rtol=1e-3), k
+
+
+def test_validate_matches_oracle(lut):
+    """validate (train_search.py:435-462): no-grad gumbel path per batch, switches reset, top-1 / top-5 / loss."""
+    from tfnas_amd import search
+    o, m = _pair(lut)
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.randn(n, 3, 224, 224, generator=g) for n in (4, 4, 3)]
+    ys = [torch.randint(0, 6, (x.size(0),), generator=g) for x in xs]
+    with torch.no_grad():
+        for mod in (o, m):
+            mod.classifier.linear.bias[:6] += 2.0
+    noise = [torch.empty(18, 8).exponential_(generator=g) for _ in xs]
+    o1, o5, ol, oidx = orc.validate(o, list(zip(xs, ys)), noise)
+
+    class _Fixed:
+        def __init__(self, rows):
+            self.rows = list(rows)
+        def exp(self, dev):
+            return self.rows.pop(0).to(dev)
+    wrapped = search.TfnasDataParallel(m)                       # the reference calls validate on the wrapped model
+    p1, p5, pl = search.validate(wrapped, list(zip(xs, ys)), noise=_Fixed(noise))
+    assert abs(p1 - o1) < 1e-3 and abs(p5 - o5) < 1e-3 and abs(pl - ol) < 1e-3
+    assert all(all(c.switches) for c in m.cells())
+    assert list(wrapped.state_dict().keys())[0].startswith('module.')
+    for p in m.parameters():
+        assert p.grad is None

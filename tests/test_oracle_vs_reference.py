@@ -214,3 +214,35 @@ def test_warmup_loop_matches_reference_train_wo_arch(ref, lut):
         orc.w_step(om, x, y, oopt_w, 5.0, noise_g=n, bi_sampling=False)
     for (k, pr), (_, po) in zip(rm.named_parameters(), om.named_parameters()):
         assert torch.allclose(pr, po, atol=2e-5, rtol=1e-4), k
+
+
+def test_validate_matches_reference_validate(ref, lut):
+    """The reference's own validate() (AST-sliced, train_search.py:435-462) vs oracle.validate and vs the product's
+    search.validate driven with the oracle model (its loop logic is model-agnostic)."""
+    import types
+    from tfnas_amd import search
+    args = types.SimpleNamespace(print_freq=1e9)
+    ts = _refload.slice_train_search(('validate',), dict(args=args, AverageMeter=ref.AverageMeter, accuracy=ref.accuracy))
+    rm, om = _build_pair(ref, lut)
+    g = torch.Generator().manual_seed(31)
+    xs = [torch.randn(n, 3, 224, 224, generator=g) for n in (3, 2, 3)]          # ragged last batches: weighted averages
+    ys = [torch.randint(0, 5, (x.size(0),), generator=g) for x in xs]
+    with torch.no_grad():                       # make top-1/top-5 non-trivial: bias the classifier towards classes 0..4
+        for m in (rm, om):
+            m.classifier.linear.bias[:5] += 2.0
+    noise = [torch.empty(18, 8).exponential_(generator=g) for _ in xs]
+    with _refload.inject_gumbel([r for n in noise for r in n]):
+        r_top1 = ts['validate']([(x.as_subclass(_CudaNoop), y.as_subclass(_CudaNoop)) for x, y in zip(xs, ys)], _Wrap(rm),
+                                torch.nn.CrossEntropyLoss())
+    o1, o5, ol, _ = orc.validate(om, list(zip(xs, ys)), noise)
+    assert abs(r_top1 - o1) < 1e-4
+    assert all(all(c.switches) for c in om.cells())
+
+    class _Fixed:                               # NoiseSource stand-in replaying the same draws
+        def __init__(self, rows):
+            self.rows = list(rows)
+        def exp(self, dev):
+            return self.rows.pop(0)
+    p1, p5, pl = search.validate(om, list(zip(xs, ys)), noise=_Fixed(noise))
+    assert abs(p1 - o1) < 1e-4 and abs(p5 - o5) < 1e-4 and abs(pl - ol) < 1e-5
+    assert 0.0 < p5 <= 100.0

@@ -64,6 +64,36 @@ static int side_join(SideCtx* c, hipStream_t main) {
     return (int)e;
 }
 
+// Joins the side stream on every exit path of tfnas_mixedop_bwd: an early error return must not leave weight-gradient
+// kernels running on buffers the caller is about to free.
+struct SideJoinGuard {
+    SideCtx* c = nullptr;
+    hipStream_t main = nullptr;
+    bool joined = false;
+    int join() {
+        joined = true;
+        return side_join(c, main);
+    }
+    ~SideJoinGuard() {
+        if (!joined && c) {
+            if (side_join(c, main) != 0) (void)hipStreamSynchronize(c->side);
+        }
+    }
+};
+
+extern "C" int tfnas_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (SideCtx* c : g_side) {
+        (void)hipStreamSynchronize(c->side);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(c->fork[i]);
+        (void)hipEventDestroy(c->join);
+        (void)hipStreamDestroy(c->side);
+        delete c;
+    }
+    g_side.clear();
+    return 0;
+}
+
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
 extern "C" uint64_t tfnas_sizeof(int which) {
@@ -234,6 +264,9 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     if (!dx && !d.need_wgrad) return 0;
     // weight gradients: on the library's side stream (see SideCtx), scratch = second half of `part`
     SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
+    SideJoinGuard guard;
+    guard.c = sc;
+    guard.main = s;
     float* part_w = part + TFNAS_PART_FLOATS;
     if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part_w, side_fork(sc, 0, s)));
     TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
@@ -260,7 +293,7 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
         TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
         TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, dout, wmix, dx, dxp, s));
     }
-    return side_join(sc, s);
+    return guard.join();
 }
 
 extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E, double* stats, float* part,

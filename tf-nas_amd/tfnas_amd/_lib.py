@@ -39,6 +39,7 @@ class TfnasCellWs(C.Structure):
 _P = C.c_void_p
 _PROTOS = {
     'tfnas_abi_version': (C.c_int, []),
+    'tfnas_shutdown': (C.c_int, []),
     'tfnas_sizeof': (C.c_uint64, [C.c_int]),
     'tfnas_cell_plan': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_cell_ws': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasCellWs)]),

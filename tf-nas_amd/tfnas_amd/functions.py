@@ -25,8 +25,35 @@ EFREE = os.environ.get('TFNAS_EFREE', '1') != '0'
 EFREE_STRIDE1 = os.environ.get('TFNAS_EFREE_STRIDE1', '0') == '1'
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev):
+    """Current HIP stream OF THE TENSORS' DEVICE (not of torch's current device)."""
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
+def _on(dev):
+    """Device guard for a launch: the C side launches on HIP's *current* device, which must be the tensors' device.
+    Free when it already is (the one-process-per-GPU case)."""
+    return _NULL if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
+def _same_device(dev, tensors, what):
+    """The C side launches on one device with raw pointers: every operand must live there."""
+    for t in tensors:
+        if t is not None and t.device != dev:
+            raise RuntimeError('tfnas_amd: %s lives on %s but the input is on %s -- all operands of a launch must share '
+                               'one device (one process per GPU; nn.DataParallel replicas must own their parameters)'
+                               % (what, t.device, dev))
 
 
 def _nhwc(x):
@@ -101,6 +128,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
             raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
     plan.bind(d, params)
     dev = xh.device
+    _same_device(dev, list(params) + [wmix], 'a MixedOP weight / mix weight')
     # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
     # cells never materialise the expanded tensor -- the depthwise kernels recompute it from x
     efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and not any(ctx.needs_input_grad[3:])
@@ -114,8 +142,9 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
     if wmix is not None:
         wmix = wmix.contiguous()
-    check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                       ptr(stats), ptr(part), ptr(out), _stream()), 'tfnas_mixedop_fwd')
+    with _on(dev):
+        check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                           ptr(stats), ptr(part), ptr(out), _stream(dev)), 'tfnas_mixedop_fwd')
     ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
     ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
     return out.permute(0, 3, 1, 2)
@@ -141,9 +170,11 @@ def _cell_backward(ctx, dout, want_dx):
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
-    check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                       ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
-                                       ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream()), 'tfnas_mixedop_bwd')
+    _same_device(dev, [douth], 'the output gradient')
+    with _on(dev):
+        check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                           ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
+                                           ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream(dev)), 'tfnas_mixedop_bwd')
     d.need_wgrad = 0
     if MixedOpFn.debug_sink is not None:
         MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
@@ -206,8 +237,10 @@ class HeadFn(torch.autograd.Function):
         stats = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
         part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         pooled = torch.empty((N, d.g[0].mc), device=dev, dtype=torch.float32)
-        check(_lib.lib().tfnas_head_fwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(part), ptr(pooled), _stream()),
-              'tfnas_head_fwd')
+        _same_device(dev, [w], 'the feature_mix weight')
+        with _on(dev):
+            check(_lib.lib().tfnas_head_fwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(part), ptr(pooled),
+                                            _stream(dev)), 'tfnas_head_fwd')
         ctx.plan, ctx.shape = plan, (N, H, W)
         ctx.save_for_backward(xh, E, stats, w)
         return pooled
@@ -227,8 +260,10 @@ class HeadFn(torch.autograd.Function):
         part = torch.empty(ws.part, device=dev, dtype=torch.float32)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
         dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32)
-        check(_lib.lib().tfnas_head_bwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(dpooled.contiguous()), ptr(dEh),
-                                        ptr(cb1), ptr(red), ptr(part), ptr(dx), ptr(dxp), _stream()), 'tfnas_head_bwd')
+        with _on(dev):
+            check(_lib.lib().tfnas_head_bwd(C.byref(d), ptr(xh), ptr(E), ptr(stats), ptr(dpooled.contiguous()), ptr(dEh),
+                                            ptr(cb1), ptr(red), ptr(part), ptr(dx), ptr(dxp), _stream(dev)),
+                  'tfnas_head_bwd')
         d.need_wgrad = 0
         return None, dx.permute(0, 3, 1, 2), gw
 
@@ -252,8 +287,10 @@ class ArchFn(torch.autograd.Function):
         lat = lat.contiguous().float()
         w = torch.empty((ncell, 8), device=dev, dtype=torch.float32)
         cl = torch.empty((ncell,), device=dev, dtype=torch.float32)
-        check(_lib.lib().tfnas_arch_fwd(ncell, ptr_array(log_alphas), ptr(e), ptr(lat), float(T), ptr(w), ptr(cl),
-                                        _stream()), 'tfnas_arch_fwd')
+        _same_device(dev, list(log_alphas) + [lat], 'an architecture parameter / latency table')
+        with _on(dev):
+            check(_lib.lib().tfnas_arch_fwd(ncell, ptr_array(log_alphas), ptr(e), ptr(lat), float(T), ptr(w), ptr(cl),
+                                            _stream(dev)), 'tfnas_arch_fwd')
         ctx.save_for_backward(w, lat)
         ctx.T, ctx.ncell = float(T), ncell
         return w, cl
@@ -264,8 +301,9 @@ class ArchFn(torch.autograd.Function):
         dla = [torch.empty(8, device=w.device, dtype=torch.float32) for _ in range(ctx.ncell)]
         dw = None if dw is None else dw.contiguous()
         dcl = None if dcl is None else dcl.contiguous()
-        check(_lib.lib().tfnas_arch_bwd(ctx.ncell, ptr(w), ptr(lat), ptr(dw), ptr(dcl), ctx.T, ptr_array(dla),
-                                        _stream()), 'tfnas_arch_bwd')
+        with _on(w.device):
+            check(_lib.lib().tfnas_arch_bwd(ctx.ncell, ptr(w), ptr(lat), ptr(dw), ptr(dcl), ctx.T, ptr_array(dla),
+                                            _stream(w.device)), 'tfnas_arch_bwd')
         return (None, None, None) + tuple(dla)
 
 
@@ -278,8 +316,10 @@ def arch_sample(log_alphas, masks, e, T, mode):
     mask_t = torch.tensor(masks, dtype=torch.uint8).to(dev)
     pos = torch.empty(ncell, device=dev, dtype=torch.int32)
     e = None if e is None else e.contiguous().float()
-    check(_lib.lib().tfnas_arch_sample(ncell, ptr_array(log_alphas), ptr(mask_t), ptr(e), float(T), int(mode),
-                                       ptr(pos), _stream()), 'tfnas_arch_sample')
+    _same_device(dev, list(log_alphas) + [e], 'an architecture parameter / noise tensor')
+    with _on(dev):
+        check(_lib.lib().tfnas_arch_sample(ncell, ptr_array(log_alphas), ptr(mask_t), ptr(e), float(T), int(mode),
+                                           ptr(pos), _stream(dev)), 'tfnas_arch_sample')
     return pos.cpu().tolist()
 
 
@@ -295,8 +335,10 @@ def arch_project(params):
             if p.dim() != 1 or p.numel() > 8 or not p.is_contiguous() or p.dtype != torch.float32:
                 raise RuntimeError('tfnas_amd: architecture parameters must be contiguous 1-D fp32 tensors of <= 8 elements')
         lens = (C.c_int32 * len(chunk))(*[p.numel() for p in chunk])
-        check(lib.tfnas_arch_project(len(chunk), ptr_array([p.data for p in chunk]), lens, _stream()),
-              'tfnas_arch_project')
+        _same_device(chunk[0].device, chunk, 'an architecture parameter')
+        with _on(chunk[0].device):
+            check(lib.tfnas_arch_project(len(chunk), ptr_array([p.data for p in chunk]), lens, _stream(chunk[0].device)),
+                  'tfnas_arch_project')
 
 
 class SinkFn(torch.autograd.Function):
@@ -313,8 +355,10 @@ class SinkFn(torch.autograd.Function):
         out_lat = torch.zeros((), device=dev, dtype=torch.float32)
         bw = torch.empty(K, device=dev, dtype=torch.float32)
         cl = None if cell_lat is None else cell_lat.contiguous()
-        check(_lib.lib().tfnas_sink_fwd(K, ptr(betas), ptr_array(rh), ptr(cl), rh[0].numel(), ptr(out), ptr(out_lat),
-                                        ptr(bw), _stream()), 'tfnas_sink_fwd')
+        _same_device(dev, rh + [cl], 'a stage depth output')
+        with _on(dev):
+            check(_lib.lib().tfnas_sink_fwd(K, ptr(betas), ptr_array(rh), ptr(cl), rh[0].numel(), ptr(out), ptr(out_lat),
+                                            ptr(bw), _stream(dev)), 'tfnas_sink_fwd')
         ctx.save_for_backward(bw, cl, *rh)
         ctx.K = K
         ctx.set_materialize_grads(False)      # sampled mode never uses out_lat: no zero-filled gradient for it
@@ -331,7 +375,8 @@ class SinkFn(torch.autograd.Function):
         dcl = None if cl is None else torch.empty(K, device=dev, dtype=torch.float32)
         dots = torch.empty(_lib.MAX_SINK, device=dev, dtype=torch.float64)
         dlat = None if dlat is None else dlat.contiguous()
-        check(_lib.lib().tfnas_sink_bwd(K, ptr(bw), ptr_array(rh), ptr(cl), ptr(douth), ptr(dlat), rh[0].numel(),
-                                        ptr_array(dres), ptr(dbetas), ptr(dcl), ptr(dots), _stream()),
-              'tfnas_sink_bwd')
+        with _on(dev):
+            check(_lib.lib().tfnas_sink_bwd(K, ptr(bw), ptr_array(rh), ptr(cl), ptr(douth), ptr(dlat), rh[0].numel(),
+                                            ptr_array(dres), ptr(dbetas), ptr(dcl), ptr(dots), _stream(dev)),
+                  'tfnas_sink_bwd')
         return (dbetas, dcl) + tuple(r.permute(0, 3, 1, 2) for r in dres)

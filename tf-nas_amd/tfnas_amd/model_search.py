@@ -91,6 +91,10 @@ class MixedOP(nn.Module):
     def _plan(self, idxs):
         key = tuple(idxs)
         p = self._plans.get(key)
+        if p is not None and p.blocks[0] is not self.m_ops[key[0]]:
+            # this module is a shallow copy (nn.DataParallel.replicate shares plain attributes between replicas): the
+            # cached plans hold the ORIGINAL module's blocks, i.e. another device's weights -- start a private cache
+            self._plans, p = {}, None
         if p is None:
             p = CellPlan(self.in_channels, self.out_channels, self.stride, self.act_func,
                          [self.m_ops[i] for i in idxs])
@@ -117,14 +121,18 @@ class MixedOP(nn.Module):
                 pos = arch_sample([self.log_alphas], [[int(s) for s in self.switches]],
                                   None if exp_noise is None else exp_noise.reshape(1, -1)[:, :8], self.T,
                                   _SAMPLE_MODES[mode])[0]
+            if not 0 <= pos < nactive:
+                raise ValueError('sampled position %d outside the %d switched-on candidates' % (pos, nactive))
             if mode == 'gumbel':
-                idx = pos                      # raw position (all switches are on when this mode is used)
+                idx = pos                      # raw position, exactly as the reference (model_search.py:63-64)
                 self.switches[idx] = False
             else:
                 idx = self.fink_ori_idx(pos)
                 self.reset_switches()
         elif mode == 'random':
             p = random.choice(range(nactive)) if rand_pos is None else int(rand_pos)
+            if not 0 <= p < nactive:
+                raise ValueError('random position %d outside the %d switched-on candidates' % (p, nactive))
             idx = self.fink_ori_idx(p)
             self.reset_switches()
         else:
@@ -132,7 +140,7 @@ class MixedOP(nn.Module):
         return idx
 
     def forward(self, x, sampling, mode, exp_noise=None, rand_pos=None):
-        pre, self._pre = self._pre, None
+        pre, self._pre = self._pre, None            # (consumed exactly once; Network.forward clears leftovers on error)
         if sampling:
             idx = pre if pre is not None else self.sample_index(mode, exp_noise, rand_pos)
             self.last_idx = idx
@@ -295,6 +303,7 @@ class Network(nn.Module):
             if pos is not None:                       # positions already chosen (host-side sampling of search.w_step)
                 if len(pos) != n:
                     raise ValueError('pos must hold one position per MixedOP')
+                self._require_all_switches_on()
                 for i, c in enumerate(cells):
                     c._pre = c.sample_index(mode, pos=int(pos[i]))
                 return
@@ -309,6 +318,12 @@ class Network(nn.Module):
                 c._pre = c.sample_index(mode, rand_pos=None if rand_pos is None else rand_pos[i])
         else:
             raise ValueError('invalid sampling mode...')
+
+    def _require_all_switches_on(self):
+        """Host-sampled gumbel positions are computed over all 8 candidates; a caller that skipped reset_switches()
+        (e.g. after an exception mid-step) would otherwise switch off the wrong op silently."""
+        if not all(all(c.switches) for c in self.cells()):
+            raise RuntimeError('host-sampled positions need every switch on: call reset_switches() first')
 
     def stem_features(self, x):
         """first_stem + second_stem output; may be passed back as ``forward(..., stem_out=)`` so that several forwards
@@ -327,6 +342,7 @@ class Network(nn.Module):
         cells = self.cells()
         if len(pos_g) != len(cells) or len(rand_pos) != len(cells):
             raise ValueError('pos_g / rand_pos must hold one entry per MixedOP')
+        self._require_all_switches_on()
         cur = torch.cuda.current_stream(x.device)
         feat = self._stem(x)
         side_stream.wait_stream(cur)
@@ -356,10 +372,15 @@ class Network(nn.Module):
         # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per
         # iteration pair here: MIOpen's fp32 NHWC path falls back to naive_conv_*, torch's BN backward is slow)
         x = self._stem(x) if stem_out is None else stem_out
-        self._prepare(x, sampling, mode, exp_noise, rand_pos, pos)
-        for st in self.stages():
-            x, lat = st(x, sampling, mode)
-            out_lat += lat
+        try:
+            self._prepare(x, sampling, mode, exp_noise, rand_pos, pos)
+            for st in self.stages():
+                x, lat = st(x, sampling, mode)
+                out_lat += lat
+        except BaseException:
+            for c in self.cells():           # a forward that aborts must not leave hand-down state for the next one
+                c._pre = None
+            raise
         x = self._head(x)                      # feature_mix_layer + global_avg_pooling (HIP), [N, 1280]
         x = self.classifier(x)
         return x, out_lat

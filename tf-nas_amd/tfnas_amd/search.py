@@ -51,6 +51,8 @@ class SearchState:
         self._side_stream = None
         self._alpha_host = None            # (key, pinned [ncell, 8] copy of the log_alphas, copy-done event)
         self._step_done = []               # completion events of the most recent steps (bounds host run-ahead)
+        self._pin = self._pin_ev = None
+        self._dp_check = None              # (tensor, expected) of the previous step's sampled-architecture check
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (created once per device)."""
@@ -74,11 +76,14 @@ class SearchState:
         if not la.is_cuda:
             self._alpha_host = (self._alpha_key(), la.clone(), None)
             return
-        buf = torch.empty(la.shape, dtype=la.dtype, pin_memory=True)
-        buf.copy_(la, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(la.device))
-        self._alpha_host = (self._alpha_key(), buf, ev)
+        # one pinned buffer + one event for the whole run (alpha_host() always waits for the copy before reading, and the
+        # next copy is only enqueued after the w-steps that read the previous one were issued)
+        if self._pin is None or self._pin.shape != la.shape:
+            self._pin = torch.empty(la.shape, dtype=la.dtype, pin_memory=True)
+            self._pin_ev = torch.cuda.Event()
+        self._pin.copy_(la, non_blocking=True)
+        self._pin_ev.record(torch.cuda.current_stream(la.device))
+        self._alpha_host = (self._alpha_key(), self._pin, self._pin_ev)
 
     def alpha_host(self):
         """Host copy of the log_alphas, or None when they were modified since it was staged."""
@@ -117,7 +122,10 @@ class SearchState:
 
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
-FORCE_ALLREDUCE_AT_WORLD_1 = False     # bench.py sets this under torchrun so the RCCL path is exercised even on 1 GPU
+# run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
+FORCE_ALLREDUCE_AT_WORLD_1 = os.environ.get('TFNAS_FORCE_ALLREDUCE', '0') == '1'
+_TINY = float(np.finfo(np.float32).tiny)
+ALLREDUCE_CALLS = 0                    # collectives issued by this process (tests / tools/dp_check.py)
 
 
 def allreduce_mean_(tensors, group=None):
@@ -127,6 +135,8 @@ def allreduce_mean_(tensors, group=None):
         return
     if dist.get_world_size(group) == 1 and not FORCE_ALLREDUCE_AT_WORLD_1:
         return
+    global ALLREDUCE_CALLS
+    ALLREDUCE_CALLS += 1
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / dist.get_world_size(group))
@@ -145,7 +155,8 @@ class NoiseSource:
         self.ncell = ncell
 
     def exp(self, device):
-        host = torch.empty(self.ncell, 8).exponential_(generator=self.gen)
+        # (an exact 0 would give log(0) = -inf -> NaN weights and an arbitrary argmax)
+        host = torch.empty(self.ncell, 8).exponential_(generator=self.gen).clamp_min_(_TINY)
         dev = host.to(device, non_blocking=True)
         dev._tfnas_host = host             # w_step samples the gumbel path on the host from these values
         return dev
@@ -161,7 +172,7 @@ def host_gumbel_positions(log_alphas, exp_noise, T):
     with torch's default intra-op pool -- 128 OpenMP threads on the bench host -- even these 18x8-element ops wake the
     whole pool, and its spinning workers stalled the launching thread for 50-250 ms every few steps.)"""
     la = np.asarray(log_alphas, dtype=np.float32)
-    e = np.asarray(exp_noise, dtype=np.float32)
+    e = np.maximum(np.asarray(exp_noise, dtype=np.float32), np.float32(_TINY))
     z = la - la.max(-1, keepdims=True)
     ls = z - np.log(np.exp(z).sum(-1, keepdims=True, dtype=np.float32))
     y = (ls - np.log(e)) / np.float32(T)
@@ -260,7 +271,8 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     return loss.detach(), logits_g.detach()
 
 
-def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0, noise=None, group=None):
+def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0, noise=None, group=None,
+           return_grads=False):
     """Architecture step: CE + lambda*|lat/target-1| -> backward -> (all-reduce) -> clip -> Adam -> log-softmax
     projection of alphas AND betas (train_search.py:421-422)."""
     model = state.model
@@ -273,7 +285,8 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     opt_a.zero_grad()
     loss.backward()
     allreduce_mean_([p.grad for p in state.arch if p.grad is not None], group)
-    grads = [p.grad.detach().clone() for p in state.arch]
+    # (a snapshot of the 24 unclipped gradients is 24 tiny launches on a launch-bound path: tests only)
+    grads = [p.grad.detach().clone() for p in state.arch] if return_grads else None
     if grad_clip > 0:
         nn.utils.clip_grad_norm_(state.arch, grad_clip)
     opt_a.step()
@@ -295,3 +308,81 @@ def search_iteration_pair(state, opt_w, opt_a, batches_w, batch_a, noise, target
     w_step(state, batches_w[0][0], batches_w[0][1], opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
     a_step(state, batch_a[0], batch_a[1], opt_a, target_lat, lambda_lat, grad_clip, noise.exp(dev), group=group)
     w_step(state, batches_w[1][0], batches_w[1][1], opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
+
+
+def accuracy(output, target, topk=(1,)):
+    """Top-k precision in percent (tools/utils.py:61-74 of the reference, used by train_search.py:344,387,455)."""
+    maxk = max(topk)
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.view(1, -1).expand(maxk, -1))
+    n = target.size(0)
+    return [correct[:k].reshape(-1).float().sum(0) * (100.0 / n) for k in topk]
+
+
+class AverageMeter:
+    """tools/utils.py:37-58."""
+
+    def __init__(self):
+        self.avg = self.sum = self.cnt = 0.0
+
+    def update(self, val, n=1):
+        self.sum += val * n
+        self.cnt += n
+        self.avg = self.sum / self.cnt
+
+
+def validate(state_or_model, val_queue, noise=None, criterion=None, log=None, print_freq=100):
+    """``validate`` of the reference (train_search.py:435-462): a no-grad 'gumbel' forward per batch in *train* mode
+    (batch-statistic BN: the search net has no running averages), ``reset_switches`` after every batch, running
+    loss / top-1 / top-5; returns (top1.avg, top5.avg, objs.avg) -- the reference returns top1.avg only.
+
+    ``noise``: a NoiseSource (identical draws on every rank) or None (device draws, like the reference)."""
+    model = getattr(state_or_model, 'model', state_or_model)
+    model = getattr(model, 'module', model)
+    criterion = criterion or F.cross_entropy
+    objs, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
+    model.train()                                   # (train_search.py:440-442: "disable moving average")
+    for step, (x, target) in enumerate(val_queue):
+        dev = next(model.parameters()).device
+        x = x.to(dev, non_blocking=True)
+        target = target.to(dev, non_blocking=True)
+        with torch.no_grad():
+            kw = {} if noise is None else {'exp_noise': noise.exp(dev)}
+            logits, _ = model(x, True, 'gumbel', **kw)
+            loss = criterion(logits, target)
+        model.reset_switches()
+        prec1, prec5 = accuracy(logits, target, topk=(1, 5))
+        n = x.size(0)
+        vals = torch.stack([loss.float(), prec1, prec5]).tolist()       # one device->host copy per batch (reference: 3)
+        objs.update(vals[0], n)
+        top1.update(vals[1], n)
+        top5.update(vals[2], n)
+        if log is not None and step % print_freq == 0:
+            log('VALIDATE Step: %04d Objs: %f R1: %f R5: %f' % (step, objs.avg, top1.avg, top5.avg))
+    return top1.avg, top5.avg, objs.avg
+
+
+class TfnasDataParallel(nn.Module):
+    """One-process-per-GPU stand-in for the reference's ``torch.nn.DataParallel(model).cuda()`` (train_search.py:95,158):
+    exposes ``.module`` so the call sites ``model.module.weight_parameters()`` / ``.arch_parameters()`` /
+    ``.set_temperature()`` / ``.reset_switches()`` (train_search.py:108,159,198,203,218,221,325-337) run unchanged, and
+    keeps DataParallel's ``state_dict`` key prefix ``module.`` (the epoch-boundary code indexes the checkpoint with
+    'module.stageN.blockM.m_ops.K...' keys, train_search.py:167-193,244-258).
+
+    Gradient averaging across ranks is not done by hooks here: the search steps (``w_step`` / ``a_step``) reduce the
+    sampled sub-network's gradients themselves (only ~1/4 of the parameters have a gradient in a step, and which ones is
+    known on the host before backward), see GradReducer."""
+
+    def __init__(self, module, device=None, process_group=None):
+        super().__init__()
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.module = module.to(device)
+        self.device = torch.device(device)
+        self.process_group = process_group
+
+    def forward(self, x, *args, **kwargs):
+        return self.module(x.to(self.device, non_blocking=True), *args, **kwargs)
+
+    def cuda(self, device=None):
+        return self
