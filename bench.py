@@ -347,15 +347,14 @@ def run_gpu(args):
     return result
 
 
-def run_cpu_baseline(B=32):
-    """Time the CPU oracle on a bounded sample of the same loop at the reference's batch 32 (SURVEY 8(d) "CPU baseline beside it").
-    Three legs, all reported:
+def run_cpu_baseline(leg, B=32):
+    """Time the CPU oracle on a bounded sample of the same loop at the reference's batch 32 (SURVEY 8(d) "CPU baseline beside
+    it").  Three legs, each run in its own child process with a hard wall-clock limit (cpu_baseline_subprocess):
       best     thread count probed on a short step (8/16/32/64): oneDNN scales badly past one socket on big hosts; this
                is the headline `value`: 3 warm-up + 10 timed iteration pairs;
       t8       pinned to 8 threads (comparable with the 8-vCPU build container, SURVEY 6: ~8.5 img/s): 1 warm-up + 3 pairs;
-      allcores torch.set_num_threads(os.cpu_count()): wall-clock capped at 40 s (256 threads made one pair take minutes
-               on the GPU box in round 1) -- reports whatever completed.
-    Sized so the whole leg stays around two minutes."""
+      allcores torch.set_num_threads(os.cpu_count()), 1 warm-up + 3 pairs, killed after 45 s (256 threads made ONE pair
+               take minutes on the GPU box in round 1) -- reported as null when it does not finish."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import tfnas_oracle as orc
     from tfnas_amd.latency import load_lat_lookup
@@ -380,49 +379,54 @@ def run_cpu_baseline(B=32):
         orc.a_step(model, xs[1], ys[1], opt_a, 15.0, 0.1, 5.0, noise.exp('cpu'))
         orc.w_step(model, xs[2], ys[2], opt_w, 5.0, noise.exp('cpu'), noise.rand_pos())
 
-    def leg(threads, warm, n, budget):
-        torch.set_num_threads(threads)
-        t_start = time.perf_counter()
-        for _ in range(warm):
-            pair()
-            if time.perf_counter() - t_start > budget:
-                return dict(threads=threads, pairs=0, value=None, note='warm-up exceeded %.0f s' % budget)
-        done, t0 = 0, time.perf_counter()
-        while done < n and (done == 0 or time.perf_counter() - t_start < budget):
-            pair()
-            done += 1
-        dt = (time.perf_counter() - t0) / done
-        return dict(threads=threads, pairs=done, warmup=warm, value=round(2 * B / dt, 3), ms_per_pair=round(dt * 1e3, 1))
+    if leg == 'best':
+        best_t, threads = None, 1
+        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            probe()                                  # warm-up at this thread count
+            t = probe()
+            if best_t is None or t < best_t:
+                best_t, threads = t, nt
+        warm, n = 3, 10
+    else:
+        threads, warm, n = (min(8, ncpu) if leg == 't8' else ncpu), 1, 3
+    torch.set_num_threads(threads)
+    for _ in range(warm):
+        pair()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pair()
+    dt = (time.perf_counter() - t0) / n
+    return dict(threads=threads, pairs=n, warmup=warm, value=round(2 * B / dt, 3), ms_per_pair=round(dt * 1e3, 1),
+                host_threads=ncpu, torch=torch.__version__, batch=B)
 
-    best_t, threads = None, 1
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        probe()                                  # warm-up at this thread count
-        t = probe()
-        if best_t is None or t < best_t:
-            best_t, threads = t, nt
-    best = leg(threads, 3, 10, 75.0)
-    t8 = leg(min(8, ncpu), 1, 3, 45.0)
-    allc = leg(ncpu, 1, 3, 40.0) if ncpu not in (threads, 8) else dict(threads=ncpu, note='same as another leg')
-    return dict(value=best['value'], unit='images/s', cores=threads, kind='port',
+
+def cpu_baseline_subprocess():
+    """Run the CPU legs in child processes with hard wall-clock limits so the bench line is always printed."""
+    import subprocess
+
+    def run(leg, timeout):
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', leg],
+                                 capture_output=True, text=True, timeout=timeout,
+                                 env=dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES=''))
+            for line in reversed(out.stdout.strip().splitlines()):
+                if line.startswith('{'):
+                    return json.loads(line)
+            return dict(value=None, note='failed: ' + out.stderr[-200:])
+        except subprocess.TimeoutExpired:
+            return dict(value=None, note='did not finish within %d s' % timeout)
+    best = run('best', 150)
+    t8 = run('t8', 90)
+    allc = run('allcores', 45)
+    if best.get('value') is None:
+        return dict(value=None, unit='images/s', cores=0, kind='port', sample='cpu baseline: ' + best.get('note', ''),
+                    threads8=t8, all_cores=allc)
+    return dict(value=best['value'], unit='images/s', cores=best['threads'], kind='port',
                 sample='%d iteration pairs (w-step, alpha-step, w-step) of oracle/tfnas_oracle.py at batch %d fp32 after %d '
                        'warm-up pairs; torch %s, %d threads (best of 8/16/32/64 probed) on a %d-thread host'
-                       % (best['pairs'], B, best.get('warmup', 0), torch.__version__, threads, ncpu),
-                ms_per_step=best.get('ms_per_pair'), threads8=t8, all_cores=allc, host_threads=ncpu)
-
-
-def cpu_baseline_subprocess(timeout=330):
-    """Run the CPU leg in a child process with a hard wall-clock limit so the bench line is always printed."""
-    import subprocess
-    try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True,
-                             text=True, timeout=timeout, env=dict(os.environ, CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES=''))
-        for line in reversed(out.stdout.strip().splitlines()):
-            if line.startswith('{'):
-                return json.loads(line)
-        return dict(value=None, unit='images/s', cores=0, kind='port', sample='cpu baseline failed: ' + out.stderr[-200:])
-    except subprocess.TimeoutExpired:
-        return dict(value=None, unit='images/s', cores=0, kind='port', sample='cpu baseline exceeded %d s' % timeout)
+                       % (best['pairs'], best['batch'], best['warmup'], best['torch'], best['threads'], best['host_threads']),
+                ms_per_step=best['ms_per_pair'], threads8=t8, all_cores=allc)
 
 
 def _attach_pmc_traffic(res):
@@ -451,10 +455,10 @@ def main():
     ap.add_argument('--no-dropin', action='store_true', help='skip the reference-style drop-in loop timing')
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step-half (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(run_cpu_baseline()))
+        print(json.dumps(run_cpu_baseline(args.cpu_baseline_only)))
         return
     res = run_gpu(args)
     if res is not None:
