@@ -123,7 +123,8 @@ int tfnas_abi_version(void);
 /* Destroys the library-owned side streams / events (after synchronising them).  Optional; safe to call more than once. */
 int tfnas_shutdown(void);
 
-/* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs. */
+/* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs,
+ * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs. */
 uint64_t tfnas_sizeof(int which);
 
 /* Fill the [plan] fields of a descriptor from its [in] fields.  Returns TFNAS_E* on bad geometry. */
@@ -207,6 +208,83 @@ int tfnas_sink_fwd(int K, const float *betas, const float *const *res, const flo
 int tfnas_sink_bwd(int K, const float *bw, const float *const *res, const float *cell_lat, const float *dout,
                    const float *dlat, uint64_t count, float *const *dres, float *dbetas, float *dcell_lat,
                    double *dot_scratch, void *stream);
+
+/* ================================================================================================================
+ * Path level: a whole chain of MixedOP cells + the sink-connecting stage mixes of a Network in ONE call per direction.
+ *
+ * Replaces the body of Network.forward between the stems and the head (models/model_search.py:285-297: six
+ * MixedStage.forward calls, :157-206) and its autograd backward, for one "path":
+ *   sampled mode  (every cell G = 1)  -- one of the two bi-sampling paths of train_w_arch's weight step
+ *                                        (train_search.py:375-379) or train_wo_arch's / validate's single path;
+ *   soft mode     (every cell G = 8)  -- the architecture step (train_search.py:409-413).
+ * The per-cell entry points above stay (they are what MixedOP.forward calls when a user drives the modules one by one);
+ * the path entry points exist because the per-cell route costs one Python/autograd round trip, ~10 tensor allocations
+ * and ~25 launches *per cell*, and the weight step then spends a third of its wall time waiting for the host.
+ * Differences to 18 x tfnas_mixedop_fwd/bwd + 6 x tfnas_sink_fwd/bwd (same kernels otherwise, bit-identical results):
+ *   - all buffers come from ONE caller-allocated arena (sizes from tfnas_path_plan);
+ *   - the sink gradient bw[k]*dsink is added in the dx epilogue of the following cell instead of K scaled copies per
+ *     stage and one elementwise add per block;
+ *   - weight-gradient kernels run on a side stream and may lag ONE cell behind the data-gradient chain (the per-cell
+ *     entry joins at the end of every cell);
+ *   - several paths (the two bi-sampling paths) are enqueued interleaved, cell by cell, on their own streams.
+ * ================================================================================================================ */
+#define TFNAS_MAX_STAGES 8
+
+typedef struct TfnasStage {
+    int32_t ncell;          /* MixedOP blocks of this stage (model_search.py:126-155: 2,3,4,4,4,1)            [in] */
+    int32_t start_res;      /* 0: the stage input is itself a depth choice (ic==oc && stride==1), else 1      [in] */
+    int32_t first_cell;     /* index of the stage's first cell in TfnasPathDesc.cell                          [plan] */
+    int32_t nres;           /* ncell + 1 - start_res = len(betas)                                            [plan] */
+    const float *betas;     /* device float[nres]                                                            [in] */
+    float *dbetas;          /* device float[nres] or NULL (architecture parameters frozen: weight step)       [in] */
+} TfnasStage;
+
+typedef struct TfnasPathDesc {
+    int32_t ncell, nstage;
+    int32_t soft;           /* 1: cells carry G = 8 groups, wmix/cell_lat are consumed and d wmix / d cell_lat produced */
+    int32_t need_dx0;       /* backward produces the gradient of the path input                               */
+    int32_t efree_mask_lo;  /* bit c set: cell c runs E-free (E never materialised; needs tfnas_efree_supported) */
+    int32_t pad0;
+    TfnasStage stage[TFNAS_MAX_STAGES];
+    TfnasCellDesc cell[TFNAS_MAX_CELLS];   /* [in] fields + weight / gradient pointers bound; N, H, W chained by plan */
+} TfnasPathDesc;
+
+/* Arena requirement of a planned path, in floats (the arena must be 256-byte aligned). */
+typedef struct TfnasPathWs {
+    uint64_t saved;         /* forward results kept for backward (E, D, Pr, small tensors, statistics, cell / stage outputs) */
+    uint64_t scratch;       /* forward + backward scratch (partials, dZ, dEh, gradient ring)                  */
+    uint64_t total;         /* saved + scratch                                                                */
+    uint64_t out_count;     /* elements of the path output [N][Ho][Wo][oc] of the last stage                  */
+    int32_t out_h, out_w, out_c, pad;
+} TfnasPathWs;
+
+/* Opaque path context: the planned descriptor, arena offsets, one library-owned side stream and the events that order
+ * it against the caller's stream.  One context per concurrently running path. */
+int tfnas_path_create(void **ctx);
+int tfnas_path_destroy(void *ctx);
+
+/* Validate + plan every cell (tfnas_cell_plan), chain the geometry (cell i+1's input extent = cell i's output), lay out
+ * the arena.  May be called again on the same context with different candidates / widths (every weight step does). */
+int tfnas_path_plan(void *ctx, const TfnasPathDesc *pd, TfnasPathWs *ws);
+
+/* Forward of `npath` planned paths, enqueued interleaved cell by cell: path p runs on streams[p] with arena[p].
+ *   x0[p]     device [N][H][W][ic0] input of the first cell (second_stem output)
+ *   wmix[p]   soft mode: device float[ncell][8] gumbel-softmax weights (tfnas_arch_fwd); NULL in sampled mode
+ *   cell_lat[p] soft mode: device float[ncell] expected cell latencies; NULL otherwise
+ *   out[p]    device [out_count] = last stage's sink output;  out_lat[p]: device float[nstage] per-stage expected latency
+ *             (soft mode; NULL otherwise). */
+int tfnas_paths_fwd(int npath, void *const *ctx, const float *const *x0, const float *const *wmix,
+                    const float *const *cell_lat, float *const *arena, float *const *out, float *const *out_lat,
+                    void *const *streams);
+
+/* Backward of the same.  dout[p]: gradient of out[p];  dout_lat[p]: device float[nstage] or NULL;
+ * produces dx0[p] (if need_dx0), dwmix[p] float[ncell][8] and dcell_lat[p] float[ncell] (soft mode), stage dbetas, and the
+ * cells' weight gradients at the g_* pointers of the planned descriptors (need_wgrad cells).
+ * On return every path's side stream has been joined to its stream. */
+int tfnas_paths_bwd(int npath, void *const *ctx, const float *const *x0, const float *const *wmix,
+                    const float *const *cell_lat, float *const *arena, const float *const *dout,
+                    const float *const *dout_lat, float *const *dx0, float *const *dwmix, float *const *dcell_lat,
+                    void *const *streams);
 
 /* ---- optional diagnostics (used by bench.py for the `roofline` object) --------------------------------------
  * Per-kernel-family timing with HIP events recorded on the launch stream.  tfnas_prof_enable(mask) turns the

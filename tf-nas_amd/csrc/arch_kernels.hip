@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_sink_bwd(int K, const float* __restrict
             if (k < K) {
                 const f32x4 r = ld4(ptrs.res[k] + 4 * i);
                 dot[k] += (dv.x * r.x + dv.y * r.y) + (dv.z * r.z + dv.w * r.w);
-                st4(ptrs.dres[k] + 4 * i, splat4(b[k]) * dv);
+                if (ptrs.dres[k]) st4(ptrs.dres[k] + 4 * i, splat4(b[k]) * dv);
             }
         }
     }
@@ -273,6 +273,20 @@ int launch_sink_fwd(int K, const float* betas, const float* const* res, const fl
     for (int k = 0; k < K; ++k) pk.res[k] = res[k];
     hipLaunchKernelGGL(k_sink_fwd, dim3(stream_blocks(count / 4)), dim3(256), 0, s, K, betas, pk, cell_lat,
                        count / 4, out, out_lat, bw);
+    return (int)hipGetLastError();
+}
+
+// dst = scale[0] * src  (the last depth output's share of the sink gradient when no d betas is wanted: weight step)
+__global__ __launch_bounds__(256) void k_scale_copy(float* __restrict__ dst, const float* __restrict__ src,
+                                                    const float* __restrict__ scale, uint64_t count4) {
+    const float w = scale[0];
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (uint64_t)gridDim.x * 256)
+        st4(dst + 4 * i, splat4(w) * ld4(src + 4 * i));
+}
+
+int launch_scale_copy(float* dst, const float* src, const float* scale, uint64_t count, hipStream_t s) {
+    ProfScope _prof(TK_SMALL, s);
+    hipLaunchKernelGGL(k_scale_copy, dim3(stream_blocks(count / 4)), dim3(256), 0, s, dst, src, scale, count / 4);
     return (int)hipGetLastError();
 }
 

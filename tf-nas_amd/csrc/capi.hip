@@ -3,6 +3,7 @@
 #include <string.h>
 #include "tfnas_dev.h"
 #include "kernels.h"
+#include "cell_impl.h"
 
 #include <stdlib.h>
 #include <mutex>
@@ -97,7 +98,15 @@ extern "C" int tfnas_shutdown(void) {
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
 extern "C" uint64_t tfnas_sizeof(int which) {
-    return which == 0 ? sizeof(TfnasGroup) : which == 1 ? sizeof(TfnasCellDesc) : which == 2 ? sizeof(TfnasCellWs) : 0;
+    switch (which) {
+        case 0: return sizeof(TfnasGroup);
+        case 1: return sizeof(TfnasCellDesc);
+        case 2: return sizeof(TfnasCellWs);
+        case 3: return sizeof(TfnasStage);
+        case 4: return sizeof(TfnasPathDesc);
+        case 5: return sizeof(TfnasPathWs);
+        default: return 0;
+    }
 }
 
 extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
@@ -198,6 +207,94 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
 
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One cell, forward / backward: the launch sequences shared by the per-cell entry points below and by the path level
+// (path.hip).
+int cell_fwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s) {
+    double* stats1 = b.stats + ws.off_stats1;
+    double* stats2 = b.stats + ws.off_stats2;
+    double* stats3 = b.stats + ws.off_stats3;
+    float* pooled = b.fsmall + ws.off_pooled;
+    float* gate = b.fsmall + ws.off_gate;
+    float* hpre = b.fsmall + ws.off_hpre;
+    if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));          // 1x1 expand (all groups) + BN1 statistics
+    else TRY(launch_expand_stats_gram(d, b.x, stats1, b.part, s));            // E-free: BN1 statistics from the Gram matrix of x
+    TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));          // BN1+act fused load, depthwise, BN2 statistics
+    TRY(launch_se_pool(d, b.D, stats2, pooled, s));                           // SE squeeze (SE groups only)
+    TRY(launch_se_fc_fwd(d, pooled, hpre, gate, b.part, TFNAS_PART_FLOATS, s));    // SE excite (K-split partials in `part`)
+    TRY(launch_project_fwd(d, b.D, gate, stats2, b.Pr, stats3, b.part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
+    TRY(launch_mix_fwd(d, b.Pr, stats3, b.wmix, b.x, b.out, s));              // sum_g w_g BN3(.) + residual
+    return 0;
+}
+
+// make `side` wait for everything enqueued on `main` so far; returns the stream to launch on
+static hipStream_t fork_to(const CellSide* so, int k, hipStream_t main) {
+    if (!so || !so->side) return main;
+    if (hipEventRecord(so->fork[k], main) != hipSuccess || hipStreamWaitEvent(so->side, so->fork[k], 0) != hipSuccess)
+        return main;
+    return so->side;
+}
+
+int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBufs& b, hipStream_t s, const CellSide* so) {
+    const double* stats1 = b.stats + ws.off_stats1;
+    const double* stats2 = b.stats + ws.off_stats2;
+    const double* stats3 = b.stats + ws.off_stats3;
+    const float* pooled = b.fsmall + ws.off_pooled;
+    const float* gate = b.fsmall + ws.off_gate;
+    const float* hpre = b.fsmall + ws.off_hpre;
+    float* dgate = b.bsmall + ws.off_dgate;
+    float* dpooled = b.bsmall + ws.off_dpooled;
+    float* dgl = b.bsmall + ws.off_dgl;
+    float* dhpre = b.bsmall + ws.off_dhpre;
+    float* cb1 = b.bsmall + ws.off_cb1;
+    double* red3 = b.red + ws.off_red3;
+    double* red2 = b.red + ws.off_red2;
+    double* red1 = b.red + ws.off_red1;
+    float* part = b.part;
+    float* part_w = b.part_w;
+
+    if (d.need_wgrad) {
+        for (int g = 0; g < d.G; ++g) {
+            const TfnasGroup& gr = d.g[g];
+            if (!gr.g_expand || !gr.g_dw || !gr.g_proj) return TFNAS_ENULL;
+            if (gr.se > 0 && (!gr.g_se_r || !gr.gb_se_r || !gr.g_se_e || !gr.gb_se_e)) return TFNAS_ENULL;
+        }
+    }
+    TRY(launch_mix_bwd_stats(d, b.dout, b.Pr, stats3, b.x, red3, part, s));           // BN3 backward sums (+ d wmix)
+    if (b.dwmix) TRY(launch_mix_dw(d, red3, b.red + ws.off_resdot, b.dwmix, s));
+    // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
+    // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
+    if (!b.dx && !d.need_wgrad) return 0;
+    // weight gradients: on the side stream, scratch = part_w
+    if (d.need_wgrad)
+        TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, fork_to(so, 0, s)));
+    TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s)); // dZ = dP W_proj
+    const bool fused2 = bn2_fused_fits(d);
+    if (fused2) TRY(launch_bn2_pool(d, b.dZ, b.D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
+    else TRY(launch_se_bwd_reduce(d, b.dZ, b.D, stats2, dgate, s));             // SE groups: d gate
+    // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
+    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)d.N * d.H * d.W * d.M, s));
+    if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
+    else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
+    if (d.need_wgrad) {
+        // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
+        // host-bound w-step; cells without SE launch nothing for it)
+        hipStream_t sw = fork_to(so, 1, s);
+        if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
+        TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
+    }
+    // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
+    TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
+    if (b.dx && d.mode != TFNAS_MODE_STEM) {
+        // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
+        float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
+        TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
+        TRY(launch_expand_dgrad(d, b.dEh, b.x, cb1, gram, b.dout, b.wmix, b.dx, b.dxp, s, b.add_src, b.add_scale));
+    }
+    return 0;
+}
+
 extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const float* wmix, float* E, float* D,
                                  float* Pr, float* fsmall, double* stats, float* part, float* out, void* stream) {
     if (!dp || !x || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
@@ -206,21 +303,8 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     if (!E && !efree_supported(d)) return TFNAS_ENULL;       // E may be omitted only in E-free mode (tfnas_efree_supported)
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
-    hipStream_t s = S(stream);
-    double* stats1 = stats + ws.off_stats1;
-    double* stats2 = stats + ws.off_stats2;
-    double* stats3 = stats + ws.off_stats3;
-    float* pooled = fsmall + ws.off_pooled;
-    float* gate = fsmall + ws.off_gate;
-    float* hpre = fsmall + ws.off_hpre;
-    if (E) TRY(launch_expand_fwd(d, x, E, stats1, part, s));          // 1x1 expand (all groups) + BN1 statistics
-    else TRY(launch_expand_stats_gram(d, x, stats1, part, s));        // E-free: BN1 statistics from the Gram matrix of x
-    TRY(launch_dw_fwd(d, E, x, stats1, D, stats2, part, s)); // BN1+act fused load, depthwise, BN2 statistics
-    TRY(launch_se_pool(d, D, stats2, pooled, s));         // SE squeeze (SE groups only)
-    TRY(launch_se_fc_fwd(d, pooled, hpre, gate, part, TFNAS_PART_FLOATS, s));      // SE excite (K-split partials in `part`)
-    TRY(launch_project_fwd(d, D, gate, stats2, Pr, stats3, part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
-    TRY(launch_mix_fwd(d, Pr, stats3, wmix, x, out, s));  // sum_g w_g BN3(.) + residual
-    return 0;
+    CellFwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, part, out};
+    return cell_fwd_impl(d, ws, b, S(stream));
 }
 
 extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const float* wmix, const float* E,
@@ -235,64 +319,19 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
-    const double* stats1 = stats + ws.off_stats1;
-    const double* stats2 = stats + ws.off_stats2;
-    const double* stats3 = stats + ws.off_stats3;
-    const float* pooled = fsmall + ws.off_pooled;
-    const float* gate = fsmall + ws.off_gate;
-    const float* hpre = fsmall + ws.off_hpre;
-    float* dgate = bsmall + ws.off_dgate;
-    float* dpooled = bsmall + ws.off_dpooled;
-    float* dgl = bsmall + ws.off_dgl;
-    float* dhpre = bsmall + ws.off_dhpre;
-    float* cb1 = bsmall + ws.off_cb1;
-    double* red3 = red + ws.off_red3;
-    double* red2 = red + ws.off_red2;
-    double* red1 = red + ws.off_red1;
-
-    if (d.need_wgrad) {
-        for (int g = 0; g < d.G; ++g) {
-            const TfnasGroup& gr = d.g[g];
-            if (!gr.g_expand || !gr.g_dw || !gr.g_proj) return TFNAS_ENULL;
-            if (gr.se > 0 && (!gr.g_se_r || !gr.gb_se_r || !gr.g_se_e || !gr.gb_se_e)) return TFNAS_ENULL;
-        }
-    }
-    TRY(launch_mix_bwd_stats(d, dout, Pr, stats3, x, red3, part, s));           // BN3 backward sums (+ d wmix)
-    if (dwmix) TRY(launch_mix_dw(d, red3, red + ws.off_resdot, dwmix, s));
-    // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
-    // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
-    if (!dx && !d.need_wgrad) return 0;
     // weight gradients: on the library's side stream (see SideCtx), scratch = second half of `part`
     SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
     SideJoinGuard guard;
     guard.c = sc;
     guard.main = s;
-    float* part_w = part + TFNAS_PART_FLOATS;
-    if (d.need_wgrad) TRY(launch_project_wgrad(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part_w, side_fork(sc, 0, s)));
-    TRY(launch_project_dgrad(d, dout, Pr, stats3, red3, wmix, dZ, s)); // dZ = dP W_proj
-    const bool fused2 = bn2_fused_fits(d);
-    if (fused2) TRY(launch_bn2_pool(d, dZ, D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
-    else TRY(launch_se_bwd_reduce(d, dZ, D, stats2, dgate, s));             // SE groups: d gate
-    // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
-    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, dEh, (size_t)d.N * d.H * d.W * d.M, s));
-    if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
-    else TRY(launch_bn2_bwd(d, dZ, D, stats2, gate, dpooled, red2, part, s));
-    if (d.need_wgrad) {
-        // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
-        // host-bound w-step; cells without SE launch nothing for it)
-        hipStream_t sw = side_fork(sc, 2, s);
-        if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
-        TRY(launch_dw_wgrad(d, dZ, gate, dpooled, D, stats2, red2, E, stats1, part_w, sw));
+    CellSide so = {};
+    if (sc) {
+        so.side = sc->side;
+        for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
     }
-    // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
-    TRY(launch_dw_bwd_data(d, dZ, gate, dpooled, D, stats2, red2, E, x, stats1, dEh, red1, part, s, cb1));
-    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part_w, side_fork(sc, 3, s)));
-    if (dx && d.mode != TFNAS_MODE_STEM) {
-        // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
-        float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
-        TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
-        TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, dout, wmix, dx, dxp, s));
-    }
+    CellBwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_FLOATS,
+                     dx, dxp, dwmix, nullptr, nullptr};
+    TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
     return guard.join();
 }
 

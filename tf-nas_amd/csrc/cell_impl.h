@@ -1,0 +1,34 @@
+// Launch sequences of ONE cell, shared by the per-cell C entry points (capi.hip) and the path level (path.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tfnas_hip.h"
+
+struct CellFwdBufs {
+    const float* x;
+    const float* wmix;
+    float *E, *D, *Pr, *fsmall;
+    double* stats;
+    float* part;
+    float* out;
+};
+
+struct CellBwdBufs {
+    const float *x, *wmix, *E, *D, *Pr, *fsmall;
+    const double* stats;
+    const float* dout;
+    float *dZ, *dEh, *bsmall;
+    double* red;
+    float *part, *part_w;        // scratch of the data-gradient chain / of the weight-gradient kernels
+    float *dx, *dxp, *dwmix;
+    const float* add_src;        // optional extra addend of dx: dx += add_scale[0] * add_src  (sink-connecting gradient,
+    const float* add_scale;      //   same shape as dx; models/model_search.py:202-204 backward)
+};
+
+// where the weight-gradient kernels of a cell go: `side` == nullptr -> the caller's stream
+struct CellSide {
+    hipStream_t side;
+    hipEvent_t fork[3];
+};
+
+int cell_fwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s);
+int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBufs& b, hipStream_t s, const CellSide* so);

@@ -357,6 +357,19 @@ __device__ __forceinline__ f32x4 bn1_de(const f32x4* cb, f32x4 deh, f32x4 e) {
     return r;
 }
 
+// dx + w*g with the product rounded separately (what the sink's scaled copy followed by autograd's add computed before the
+// two were folded into this epilogue): keeps the path level bit-identical to the per-cell route
+__device__ __forceinline__ f32x4 sink_add(f32x4 v, float w, f32x4 g) {
+    // the product must be rounded on its own: -ffp-contract=fast would fuse it into the add (HIP's __fmul_rn / __fadd_rn
+    // are plain * and +, and `#pragma clang fp contract(off)` did not survive inlining here) -- the empty asm makes each
+    // product opaque to the contraction pass
+    float px = w * g.x, py = w * g.y, pz = w * g.z, pw = w * g.w;
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(pw));
+    f32x4 r;
+    r.x = v.x + px; r.y = v.y + py; r.z = v.z + pz; r.w = v.w + pw;
+    return r;
+}
+
 // ============================================================================ expand dgrad, without reading E
 // dx[p][c] = sum_m de[p][m] * W[m][c]  (+ sumw * dout[p][c] for residual cells),  m over all mid channels of all groups,
 //   de = rstd * (deh - t1 - ehat*t2),  ehat = (E - mu) * rstd,  (mu, rstd, t1, t2) = cb1[m]   (BN1 backward).
@@ -373,7 +386,9 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
                                                       const float* __restrict__ x, const float* __restrict__ cb1,
                                                       const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
-                                                      float* __restrict__ dxp, int nsplit) {
+                                                      float* __restrict__ dxp, int nsplit,
+                                                      const float* __restrict__ add_src,
+                                                      const float* __restrict__ add_scale) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     const int n0 = blockIdx.y * T::BN;
@@ -387,6 +402,8 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
     const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
     float* __restrict__ dst = nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx;
     const bool add_res = d.has_res && nsplit == 1;
+    const bool add_sink = add_src != nullptr && nsplit == 1;
+    const float sink_w = add_src ? add_scale[0] : 0.f;
     float sumw = 1.f;
     if (wmix) {
         sumw = 0.f;
@@ -435,16 +452,20 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
             if (p < P && c < ic) {
                 if (nsplit == 1) v += ld4(gram + (size_t)ic * ic + c);
                 if (add_res) v += splat4(sumw) * ld4(dout + (size_t)p * d.oc + c);
+                if (add_sink) v = sink_add(v, sink_w, ld4(add_src + (size_t)p * ic + c));
                 st4(dst + (size_t)p * ic + c, v);
             }
         });
     }
 }
 
-// dx = sum_z dxp[z] + b (+ sumw * dout for residual cells)
+// dx = sum_z dxp[z] + b (+ sumw * dout for residual cells) (+ add_scale * add_src: sink-connecting gradient)
 __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float* __restrict__ dxp, int nsplit,
                                                    const float* __restrict__ gram, const float* __restrict__ dout,
-                                                   const float* __restrict__ wmix, float* __restrict__ dx) {
+                                                   const float* __restrict__ wmix, float* __restrict__ dx,
+                                                   const float* __restrict__ add_src,
+                                                   const float* __restrict__ add_scale) {
+    const float sink_w = add_src ? add_scale[0] : 0.f;
     const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
     const int iq = d.ic / 4;
     const float* __restrict__ bias = gram + (size_t)d.ic * d.ic;
@@ -457,6 +478,7 @@ __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float*
         f32x4 v = ld4(bias + 4 * (int)(i % iq));
         if (d.has_res) v += splat4(sumw) * ld4(dout + 4 * i);
         for (int z = 0; z < nsplit; ++z) v += ld4(dxp + (size_t)z * n4 * 4 + 4 * i);
+        if (add_src) v = sink_add(v, sink_w, ld4(add_src + 4 * i));
         st4(dx + 4 * i, v);
     }
 }
@@ -831,14 +853,16 @@ int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch,
 }
 
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
-                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s) {
+                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s,
+                        const float* add_src, const float* add_scale) {
     ProfScope _prof(TK_EXPAND_DGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit, 1u << 30, gemm_slots(nt), 4096), tiles, nsplit);
     DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit);
+        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit,
+                           add_src, add_scale);
     })
     _prof.stop();
     if (nsplit > 1) {
@@ -846,7 +870,8 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
         const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
         size_t blocks = cdiv64(n4, 256 * 2);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx);
+        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx,
+                           add_src, add_scale);
     }
     return (int)hipGetLastError();
 }

@@ -17,7 +17,8 @@ size_t expand_gram_floats(const TfnasCellDesc& d);
 int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
                        hipStream_t s);
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
-                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s);
+                        const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s,
+                        const float* add_src = nullptr, const float* add_scale = nullptr);
 int expand_dgrad_splits(const TfnasCellDesc& d);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s);
@@ -81,6 +82,8 @@ int launch_arch_sample(int ncell, const float* const* la, const uint8_t* mask, c
                        int32_t* pos, hipStream_t s);
 int launch_sink_fwd(int K, const float* betas, const float* const* res, const float* cell_lat, uint64_t count,
                     float* out, float* out_lat, float* bw, hipStream_t s);
+int launch_scale_copy(float* dst, const float* src, const float* scale, uint64_t count, hipStream_t s);
+// dres[k] may be NULL (that depth output's share is added elsewhere: path level)
 int launch_sink_bwd(int K, const float* bw, const float* const* res, const float* cell_lat, const float* dout,
                     const float* dlat, uint64_t count, float* const* dres, float* dbetas, float* dcell_lat,
                     double* dots, hipStream_t s);

@@ -36,7 +36,26 @@ class TfnasCellWs(C.Structure):
         'red', 'off_red3', 'off_red2', 'off_red1', 'off_resdot', 'part', 'dx', 'dxp')]
 
 
+MAX_STAGES = 8
+
+
+class TfnasStage(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'start_res', 'first_cell', 'nres')]
+                + [('betas', C.c_void_p), ('dbetas', C.c_void_p)])
+
+
+class TfnasPathDesc(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'nstage', 'soft', 'need_dx0', 'efree_mask_lo', 'pad0')]
+                + [('stage', TfnasStage * MAX_STAGES), ('cell', TfnasCellDesc * MAX_CELLS)])
+
+
+class TfnasPathWs(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ('saved', 'scratch', 'total', 'out_count')]
+                + [(n, C.c_int32) for n in ('out_h', 'out_w', 'out_c', 'pad')])
+
+
 _P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
 _PROTOS = {
     'tfnas_abi_version': (C.c_int, []),
     'tfnas_shutdown': (C.c_int, []),
@@ -47,6 +66,11 @@ _PROTOS = {
     'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 17),
     'tfnas_head_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
     'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
+    'tfnas_path_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'tfnas_path_destroy': (C.c_int, [C.c_void_p]),
+    'tfnas_path_plan': (C.c_int, [C.c_void_p, C.POINTER(TfnasPathDesc), C.POINTER(TfnasPathWs)]),
+    'tfnas_paths_fwd': (C.c_int, [C.c_int] + [_PP] * 8),
+    'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11),
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
@@ -77,7 +101,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if l.tfnas_abi_version() != 1:
             raise RuntimeError('tfnas_amd: ABI version mismatch')
-        for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs)):
+        for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs)):
             if l.tfnas_sizeof(which) != C.sizeof(st):
                 raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
         _lib = l
@@ -98,7 +122,15 @@ def ptr(t):
 def ptr_array(tensors):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def raw_array(values):
+    """(void* x n) from raw integers / None."""
+    arr = (C.c_void_p * len(values))()
+    for i, v in enumerate(values):
+        arr[i] = v
     return arr
 
 

@@ -228,6 +228,7 @@ class Network(nn.Module):
         self.classifier = LinearLayer(1280, num_classes)
         self._initialization()
         self._cells = None
+        self._lat_stack = None
         self._stem_plan = None
         self._head_plan = None
 
@@ -276,24 +277,33 @@ class Network(nn.Module):
             self._cells = [blk for st in self.stages() for blk in st.blocks()]
         return self._cells
 
+    def arch_weights(self, size, dev, exp_noise=None):
+        """(W [ncell, 8], CL [ncell]): gumbel-softmax weights of every cell and their expected latencies for a stem output
+        of spatial ``size`` -- F.gumbel_softmax + get_lookup_latency + sum(w*lat) of MixedOP.forward (model_search.py:87-90)
+        for the whole network in one launch."""
+        cells = self.cells()
+        if exp_noise is None:
+            exp_noise = torch.empty(len(cells), 8, device=dev).exponential_()
+        key = (size, str(dev), tuple(op.mid_channels for c in cells for op in c.m_ops))
+        if self._lat_stack is None or self._lat_stack[0] != key:
+            lats = []
+            for st in self.stages():
+                for blk in st.blocks():
+                    lats.append(blk.lat_tensor(size, dev))
+                    size = (size - 1) // blk.stride + 1
+            self._lat_stack = (key, torch.stack(lats))
+        T = cells[0].T
+        if any(c.T != T for c in cells):
+            raise ValueError('all MixedOPs must share one temperature (Network.set_temperature)')
+        return ArchFn.apply(exp_noise.to(dev), self._lat_stack[1], T, *[c.log_alphas for c in cells])
+
     def _prepare(self, x, sampling, mode, exp_noise, rand_pos, pos=None):
         """All arch-parameter work of one forward in ONE launch (and at most one device->host copy)."""
         cells = self.cells()
         n = len(cells)
         dev = x.device
         if not sampling:
-            if exp_noise is None:
-                exp_noise = torch.empty(n, 8, device=dev).exponential_()
-            size = x.size(-1)
-            lats = []
-            for st in self.stages():
-                for blk in st.blocks():
-                    lats.append(blk.lat_tensor(size, dev))
-                    size = (size - 1) // blk.stride + 1
-            T = cells[0].T
-            if any(c.T != T for c in cells):
-                raise ValueError('all MixedOPs must share one temperature (Network.set_temperature)')
-            W, CL = ArchFn.apply(exp_noise.to(dev), torch.stack(lats), T, *[c.log_alphas for c in cells])
+            W, CL = self.arch_weights(x.size(-1), dev, exp_noise)
             # unbind, not W[i]: 18 selects cost 18 zero-filled [18, 8] buffers + 18 slice copies + 17 adds in backward
             # (on the alpha-step's single dependency chain); unbind's backward is one stack
             for c, w_c, cl_c in zip(cells, W.unbind(0), CL.unbind(0)):

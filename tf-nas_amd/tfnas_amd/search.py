@@ -53,6 +53,57 @@ class SearchState:
         self._step_done = []               # completion events of the most recent steps (bounds host run-ahead)
         self._pin = self._pin_ev = None
         self._dp_check = None              # (tensor, expected) of the previous step's sampled-architecture check
+        self.arena = self.runner = None
+        self._op_params = {}
+        self._shared = None
+        self._graded = []                  # parameters whose .grad was pointed into the arena by the last w-step
+        if USE_PATHS and hasattr(model, 'cells') and self.weights and self.weights[0].is_cuda \
+                and hasattr(model, 'arch_weights'):
+            self.build_paths()
+
+    def build_paths(self):
+        """(Re)build the weight arena + path runner (path.py).  Needed again after parameter storages were replaced, e.g. by
+        the reference's epoch-boundary weight slicing (train_search.py:164-193) -- w_step checks and does it lazily."""
+        from .path import PathRunner, WeightArena
+        if self.runner is not None:
+            self.runner.close()
+        self.arena = WeightArena(self.model)
+        self.runner = PathRunner(self.model, self.arena)
+        self._op_params = {}
+        cell_params = set()
+        for c in self.model.cells():
+            for op in c.m_ops:
+                cell_params.update(id(p) for p in op.parameters())
+        # parameters outside the cells (stems, head, classifier): their gradients come through autograd and are
+        # accumulated in place into zeroed arena views
+        self._shared = [p for p in self.weights if id(p) not in cell_params]
+        self._shared_spans = _merge_spans([self.arena.slot[id(p)] for p in self._shared])
+
+    def op_params(self, ci, idx):
+        key = (ci, idx)
+        ps = self._op_params.get(key)
+        if ps is None:
+            ps = self._op_params[key] = list(self.model.cells()[ci].m_ops[idx].parameters())
+        return ps
+
+    def begin_weight_grads(self):
+        """Before a path-level w-step: drop last step's gradient views, zero + attach the shared parameters' arena views."""
+        for p in self._graded:
+            p.grad = None
+        self._graded = []
+        for lo, n in self._shared_spans:
+            self.arena.g[lo:lo + n].zero_()
+        for p in self._shared:
+            p.grad = self.arena.grad_view(p)
+
+    def expose_weight_grads(self, idx_lists):
+        """After backward: point .grad of the sampled candidates' parameters at the arena ranges the kernels wrote."""
+        g = self._graded
+        for idxs in idx_lists:
+            for ci, idx in enumerate(idxs):
+                for p in self.op_params(ci, idx):
+                    p.grad = self.arena.grad_view(p)
+                    g.append(p)
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (created once per device)."""
@@ -120,6 +171,20 @@ class SearchState:
             self._mode = (weights, arch)
 
 
+def _merge_spans(slots, align=64):
+    """[(offset, numel)] -> merged [(offset, padded length)] of adjacent arena slots."""
+    out = []
+    for o, n in sorted(slots):
+        ln = (n + align - 1) // align * align
+        if out and out[-1][0] + out[-1][1] == o:
+            out[-1] = (out[-1][0], out[-1][1] + ln)
+        else:
+            out.append((o, ln))
+    return out
+
+
+# one C call per direction for a whole path (path.py) instead of one autograd node per cell; TFNAS_PATHS=0: per-cell route
+USE_PATHS = os.environ.get('TFNAS_PATHS', '1') != '0'
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
@@ -198,6 +263,8 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     # the reference runs the stems twice with identical results.  Only the HIP model exposes stem_features().
     overlap = bi_sampling and overlap_paths and x.is_cuda
     host_e = getattr(noise_g, '_tfnas_host', None) if HOST_SAMPLING else None
+    if state.runner is not None and USE_PATHS and overlap_paths and (not bi_sampling or rand_pos is not None):
+        return _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos, bi_sampling, group)
     if INTERLEAVE_PATHS and overlap and host_e is not None and rand_pos is not None and hasattr(model, 'forward_bisample'):
         # fast path: positions known on the host -> both paths in one interleaved sweep (see forward_bisample)
         cur = torch.cuda.current_stream(x.device)
@@ -271,6 +338,68 @@ def w_step(state, x, target, opt_w, grad_clip=5.0, noise_g=None, rand_pos=None, 
     return loss.detach(), logits_g.detach()
 
 
+def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos, bi_sampling, group):
+    """w_step on the path level: stems -> ONE node for the sampled path(s) -> head(s); weight gradients of the cells land
+    in the WeightArena, everything else is unchanged (same kernels, same clip / SGD)."""
+    model, runner = state.model, state.runner
+    dev = x.device
+    if not state.arena.intact():
+        state.build_paths()
+        runner = state.runner
+    cells = model.cells()
+    T = cells[0].T
+    if host_e is not None:
+        model._require_all_switches_on()
+        pos_g = host_gumbel_positions(state.alpha_host(), host_e, T)
+    else:                                   # noise lives on the device (or is to be drawn there): one blocking copy
+        from .functions import arch_sample
+        e = noise_g if noise_g is not None else torch.empty(len(cells), 8, device=dev).exponential_()
+        pos_g = arch_sample([c.log_alphas for c in cells], [[int(s) for s in c.switches] for c in cells], e.to(dev), T, 0)
+    idx_a = [c.sample_index('gumbel', pos=int(p)) for c, p in zip(cells, pos_g)]
+    idx_b = None
+    if bi_sampling:
+        idx_b = [c.sample_index('random', rand_pos=p) for c, p in zip(cells, rand_pos)]
+    else:
+        model.reset_switches()
+    for c, ia in zip(cells, idx_a if idx_b is None else idx_b):
+        c.last_idx = ia
+    opt_w.zero_grad()
+    state.begin_weight_grads()
+    feat = model._stem(x)
+    if bi_sampling:
+        cur = torch.cuda.current_stream(dev)
+        side = state.side_stream(dev)
+        oa, ob = runner.bisampled(feat, idx_a, idx_b, side)
+        logits_g = model.classifier(model._head(oa))
+        loss = F.cross_entropy(logits_g, target)
+        with torch.cuda.stream(side):
+            loss_r = F.cross_entropy(model.classifier(model._head(ob)), target)
+        cur.wait_stream(side)
+        loss_r.record_stream(cur)
+        loss = loss + loss_r
+    else:
+        logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
+        loss = F.cross_entropy(logits_g, target)
+    loss.backward()
+    state.expose_weight_grads([idx_a] if idx_b is None else [idx_a, idx_b])
+    grads = [p.grad for p in state.weights if p.grad is not None]
+    allreduce_mean_(grads, group)
+    if grad_clip > 0:
+        nn.utils.clip_grad_norm_(state.weights, grad_clip)
+    opt_w.step()
+    state.mark_step(dev)
+    return loss.detach(), logits_g.detach()
+
+
+def _a_forward_paths(state, x, noise):
+    model, runner = state.model, state.runner
+    feat = model._stem(x)
+    W, CL = model.arch_weights(feat.size(-1), x.device, noise)
+    out, stage_lat = runner.soft(feat, W, CL)
+    lat = stage_lat.sum() + model.lat_lookup['base']
+    return model.classifier(model._head(out)), lat
+
+
 def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0, noise=None, group=None,
            return_grads=False):
     """Architecture step: CE + lambda*|lat/target-1| -> backward -> (all-reduce) -> clip -> Adam -> log-softmax
@@ -278,7 +407,10 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     model = state.model
     state.throttle(x.device)
     state.require(False, True)
-    logits, lat = model(x, False, exp_noise=noise)
+    if state.runner is not None and USE_PATHS:
+        logits, lat = _a_forward_paths(state, x, noise)
+    else:
+        logits, lat = model(x, False, exp_noise=noise)
     loss_a = F.cross_entropy(logits, target)
     loss_l = torch.abs(lat / target_lat - 1.) * lambda_lat
     loss = loss_a + loss_l
