@@ -286,6 +286,33 @@ int tfnas_paths_bwd(int npath, void *const *ctx, const float *const *x0, const f
                     const float *const *dout_lat, float *const *dx0, float *const *dwmix, float *const *dcell_lat,
                     void *const *streams);
 
+/* ---- fused optimizer steps ------------------------------------------------------------------
+ * Weight step tail, train_search.py:381-385: clip_grad_norm_(weight_parameters, max_norm) then SGD(momentum, weight decay,
+ * dampening 0) on the parameters that received a gradient.  w / g / m: flat fp32 arenas with identical layout (weights,
+ * gradients, momentum); (off[i], len[i]) i < nranges <= 64: the float ranges to update (multiples of 4; typically one per
+ * sampled candidate).  total = ||g over all ranges|| * grad_scale (grad_scale = 1 / world_size after a SUM all-reduce);
+ * g <- g * grad_scale * min(1, max_norm / (total + 1e-6));  m <- momentum*m + (g + wd*w);  w <- w - lr*m.
+ * max_norm <= 0 disables clipping.  scratch: device doubles, >= sum ceil(len/8192).  norm_out: device float or NULL.
+ * goff: NULL (gradients at the same offsets as the weights) or the offsets of the ranges inside `g` when `g` is the packed
+ * all-reduce message built by tfnas_pack_ranges.  Two launches, no atomics, deterministic. */
+int tfnas_sgd_clip_step(float *w, float *g, float *m, int nranges, const uint64_t *off, const uint64_t *goff, const uint64_t *len,
+                        float max_norm, float lr, float momentum, float wd, float grad_scale, double *scratch,
+                        uint64_t scratch_doubles, float *norm_out, void *stream);
+
+/* dst[doff[i] .. +len[i]) = src[off[i] .. +len[i]) for nranges <= 64 ranges (one launch): gathers the sampled candidates'
+ * gradient ranges into ONE contiguous buffer = one RCCL all-reduce message (no torch.cat, no copy back: the SGD step reads
+ * the reduced message through `goff`). */
+int tfnas_pack_ranges(const float *src, float *dst, int nranges, const uint64_t *off, const uint64_t *doff,
+                      const uint64_t *len, void *stream);
+
+/* Architecture step tail, train_search.py:414-422: clip_grad_norm_(arch_parameters, max_norm), Adam (torch semantics:
+ * weight decay added to the gradient, bias correction with `step` >= 1, eps outside the square root) and the projection
+ * p <- log_softmax(p), for n <= 32 parameters of len[i] <= 8 floats, in ONE launch.  p / g: host arrays of n device pointers;
+ * m / v: device float[n][8] Adam moments (row i, first len[i] entries). */
+int tfnas_arch_adam_project(int n, float *const *p, const float *const *g, const int32_t *len, float *m, float *v,
+                            float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+                            float grad_scale, float *norm_out, void *stream);
+
 /* ---- optional diagnostics (used by bench.py for the `roofline` object) --------------------------------------
  * Per-kernel-family timing with HIP events recorded on the launch stream.  tfnas_prof_enable(mask) turns the
  * families whose bit is set on (0 = off, the default); tfnas_prof_collect() waits for the recorded events of

@@ -23,8 +23,9 @@ def _model(lut, seed=2, T=5.0):
 
 def _run(lut, use_paths, pairs=2, B=8, warm=False):
     from tfnas_amd import search
-    old = search.USE_PATHS
+    old, old_f = search.USE_PATHS, search.FUSED_OPT
     search.USE_PATHS = use_paths
+    search.FUSED_OPT = False               # (same torch.optim tail on both sides: this test is about the path level)
     try:
         m = _model(lut)
         st = search.SearchState(m)
@@ -49,7 +50,7 @@ def _run(lut, use_paths, pairs=2, B=8, warm=False):
         torch.cuda.synchronize()
         return {k: p.detach().clone() for k, p in m.named_parameters()}, lats
     finally:
-        search.USE_PATHS = old
+        search.USE_PATHS, search.FUSED_OPT = old, old_f
 
 
 @pytest.mark.parametrize('warm', [False, True])
@@ -114,3 +115,75 @@ def test_path_plan_rejects_bad_stage_structure(lut):
     assert lib.tfnas_path_plan(ctx, C.byref(pd), C.byref(ws)) != 0
     assert lib.tfnas_path_plan(None, C.byref(pd), C.byref(ws)) == -2        # TFNAS_ENULL
     assert lib.tfnas_path_destroy(ctx) == 0
+
+
+def _run_opt(lut, fused, pairs=1, B=8):
+    from tfnas_amd import search
+    old = search.FUSED_OPT
+    search.FUSED_OPT = fused
+    try:
+        m = _model(lut)
+        st = search.SearchState(m)
+        ow, oa = search.make_optimizers(m)
+        noise = search.NoiseSource(4)
+        gen = torch.Generator(device='cuda').manual_seed(8)
+
+        def batch():
+            return (torch.randn(B, 3, 224, 224, device='cuda', generator=gen),
+                    torch.randint(0, 100, (B,), device='cuda', generator=gen))
+        # ONE w-step and ONE alpha-step from identical state: later steps amplify the last-bit differences of the two
+        # implementations (a 1e-8 weight difference moves BN statistics and ReLU masks of the next forward)
+        b0, ba = batch(), batch()
+        search.w_step(st, b0[0], b0[1], ow, 5.0, noise.exp('cuda'), noise.rand_pos())
+        search.a_step(st, ba[0], ba[1], oa, 15.0, 0.1, 5.0, noise.exp('cuda'))
+        torch.cuda.synchronize()
+        mom = {k: ow.state[p]['momentum_buffer'].clone() for k, p in m.named_parameters() if p in ow.state}
+        if fused:
+            st.export_optimizer_state(oa)
+        adam = {k: (oa.state[p]['exp_avg'].clone(), oa.state[p]['exp_avg_sq'].clone(), float(oa.state[p]['step']))
+                for k, p in m.named_parameters() if p in oa.state}
+        return {k: p.detach().clone() for k, p in m.named_parameters()}, mom, adam
+    finally:
+        search.FUSED_OPT = old
+
+
+def test_fused_clip_sgd_and_adam_projection_match_torch_optim(lut):
+    """opt_kernels.hip vs clip_grad_norm_ + torch.optim.SGD / Adam + per-tensor log_softmax (train_search.py:381-385,
+    414-422), one step of each kind from the same start: weights (<= 1e-7 + 1e-6 relative), momentum, Adam moments, step."""
+    pa, ma, aa = _run_opt(lut, True)
+    pb, mb, ab = _run_opt(lut, False)
+    for k in pa:
+        tol = 2e-6 if (k.endswith('log_alphas') or k.endswith('betas')) else 1e-7 + 1e-6 * float(pb[k].abs().max())
+        assert torch.allclose(pa[k], pb[k], atol=tol, rtol=0), (k, float((pa[k] - pb[k]).abs().max()))
+    for k in mb:
+        assert torch.allclose(ma[k], mb[k], atol=1e-7 + 1e-5 * float(mb[k].abs().max()), rtol=0), k
+    assert set(aa) == set(ab)
+    for k in ab:
+        assert aa[k][2] == ab[k][2] == 1.0
+        assert torch.allclose(aa[k][0], ab[k][0], atol=1e-7, rtol=1e-4), k
+        assert torch.allclose(aa[k][1], ab[k][1], atol=1e-9, rtol=1e-4), k
+
+
+def test_fused_steps_share_state_with_the_torch_optimizers(lut):
+    """load_state_dict on the torch optimizers (what a resume / the teacher-forced tests do) is picked up by the fused
+    steps, and a switch back to opt.step() continues from the fused state."""
+    from tfnas_amd import search
+    m = _model(lut)
+    st = search.SearchState(m)
+    ow, oa = search.make_optimizers(m)
+    noise = search.NoiseSource(1)
+    x = torch.randn(4, 3, 224, 224, device='cuda')
+    y = torch.randint(0, 100, (4,), device='cuda')
+    search.w_step(st, x, y, ow, 5.0, noise.exp('cuda'), noise.rand_pos())
+    search.a_step(st, x, y, oa, 15.0, 0.1, 5.0, noise.exp('cuda'))
+    st.export_optimizer_state(oa)
+    sd_w, sd_a = ow.state_dict(), oa.state_dict()
+    assert any(float(v['momentum_buffer'].abs().max()) > 0 for v in sd_w['state'].values())
+    ow.load_state_dict(sd_w)
+    oa.load_state_dict(sd_a)
+    search.w_step(st, x, y, ow, 5.0, noise.exp('cuda'), noise.rand_pos())       # re-binds the (replaced) state tensors
+    search.a_step(st, x, y, oa, 15.0, 0.1, 5.0, noise.exp('cuda'))
+    assert st._adam_t == 2
+    p0 = st._shared[0]
+    assert ow.state[p0]['momentum_buffer'].data_ptr() == st.arena.m.data_ptr() + 4 * st.arena.slot[id(p0)][0]
+    torch.cuda.synchronize()

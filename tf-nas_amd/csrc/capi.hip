@@ -411,3 +411,26 @@ extern "C" int tfnas_sink_bwd(int K, const float* bw, const float* const* res, c
     if (count & 3) return TFNAS_EINVAL;
     return launch_sink_bwd(K, bw, res, cell_lat, dout, dlat, count, dres, dbetas, dcell_lat, dot_scratch, S(stream));
 }
+
+extern "C" int tfnas_pack_ranges(const float* src, float* dst, int nranges, const uint64_t* off, const uint64_t* doff,
+                                 const uint64_t* len, void* stream) {
+    if (!src || !dst || !off || !doff || !len) return TFNAS_ENULL;
+    return launch_pack_ranges(src, dst, nranges, off, doff, len, S(stream));
+}
+
+extern "C" int tfnas_sgd_clip_step(float* w, float* g, float* m, int nranges, const uint64_t* off, const uint64_t* goff,
+                                   const uint64_t* len, float max_norm, float lr, float momentum, float wd, float grad_scale, double* scratch,
+                                   uint64_t scratch_doubles, float* norm_out, void* stream) {
+    if (!w || !g || !m || !off || !len || !scratch) return TFNAS_ENULL;
+    return launch_sgd_clip_step(w, g, m, nranges, off, goff, len, max_norm, lr, momentum, wd, grad_scale, scratch, scratch_doubles,
+                                norm_out, S(stream));
+}
+
+extern "C" int tfnas_arch_adam_project(int n, float* const* p, const float* const* g, const int32_t* len, float* m, float* v,
+                                       float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+                                       float grad_scale, float* norm_out, void* stream) {
+    if (!p || !g || !len || !m || !v) return TFNAS_ENULL;
+    if (step < 1) return TFNAS_EINVAL;
+    return launch_arch_adam_project(n, p, g, len, m, v, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale, norm_out,
+                                    S(stream));
+}

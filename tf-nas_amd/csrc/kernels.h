@@ -87,3 +87,14 @@ int launch_scale_copy(float* dst, const float* src, const float* scale, uint64_t
 int launch_sink_bwd(int K, const float* bw, const float* const* res, const float* cell_lat, const float* dout,
                     const float* dlat, uint64_t count, float* const* dres, float* dbetas, float* dcell_lat,
                     double* dots, hipStream_t s);
+
+// opt_kernels.hip
+int launch_pack_ranges(const float* src, float* dst, int nranges, const uint64_t* off, const uint64_t* doff,
+                       const uint64_t* len, hipStream_t s);
+int launch_sgd_clip_step(float* w, float* g, float* m, int nranges, const uint64_t* off, const uint64_t* goff,
+                         const uint64_t* len, float max_norm,
+                         float lr, float momentum, float wd, float grad_scale, double* scratch, uint64_t scratch_doubles,
+                         float* norm_out, hipStream_t s);
+int launch_arch_adam_project(int n, float* const* p, const float* const* g, const int32_t* len, float* m, float* v,
+                             float max_norm, float lr, float b1, float b2, float eps, float wd, int step, float grad_scale,
+                             float* norm_out, hipStream_t s);

@@ -220,6 +220,16 @@ extern "C" int tfnas_path_create(void** ctx) {
     PathCtx* c = new (std::nothrow) PathCtx();
     if (!c) return TFNAS_ERANGE;
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return (int)hipGetLastError(); }
+    *ctx = c;
+    return 0;
+}
+
+// The side stream and its events are created by the first backward that has weight gradients to run: HIP multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues round-robin in creation order, so every stream that exists but is never
+// used (soft-mode contexts, size probes) shifts the mapping and can put a path's data-gradient chain and its own
+// weight-gradient stream on the SAME hardware queue (measured: w-step 21 -> 23.5 ms).
+static int ensure_side(PathCtx* c) {
+    if (c->events_ok) return 0;
     hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (int i = 0; i < TFNAS_MAX_CELLS && e == hipSuccess; ++i) {
         for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->fork[i][k], hipEventDisableTiming);
@@ -227,9 +237,8 @@ extern "C" int tfnas_path_create(void** ctx) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->xfork, hipEventDisableTiming);
-    if (e != hipSuccess) { delete c; return (int)e; }      // (a failed create leaks a few events; the process is unusable anyway)
+    if (e != hipSuccess) return (int)e;       // (a failed create leaks a few events; the process is unusable anyway)
     c->events_ok = true;
-    *ctx = c;
     return 0;
 }
 
@@ -414,7 +423,10 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         r.dwmix = dwmix ? dwmix[p] : nullptr;
         r.dcell_lat = dcell_lat ? dcell_lat[p] : nullptr;
         r.s = S(streams[p]);
-        r.side_on = wgrad_side_enabled();
+        bool any_w = false;
+        for (int i = 0; i < c->pd.ncell; ++i) any_w = any_w || c->pd.cell[i].need_wgrad;
+        r.side_on = wgrad_side_enabled() && any_w;
+        if (r.side_on) TRY(ensure_side(c));
     }
     const PathCtx* c0 = run[0].c;
     int lat_off_end = 0;

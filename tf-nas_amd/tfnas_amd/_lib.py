@@ -71,6 +71,12 @@ _PROTOS = {
     'tfnas_path_plan': (C.c_int, [C.c_void_p, C.POINTER(TfnasPathDesc), C.POINTER(TfnasPathWs)]),
     'tfnas_paths_fwd': (C.c_int, [C.c_int] + [_PP] * 8),
     'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11),
+    'tfnas_pack_ranges': (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
+    'tfnas_sgd_clip_step': (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64), C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, _P, C.c_uint64, _P, _P]),
+    'tfnas_arch_adam_project': (C.c_int, [C.c_int, _PP, _PP, C.POINTER(C.c_int32), _P, _P, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P, _P]),
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),

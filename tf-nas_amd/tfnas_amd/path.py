@@ -207,12 +207,48 @@ class PathRunner:
             off += st.num_res
         check(self.lib.tfnas_path_plan(s.ctx, C.byref(pd), C.byref(s.ws)), 'tfnas_path_plan')
         if s.arena is None or s.arena.numel() < s.ws.total:
-            if s.arena is not None:
-                torch.cuda.synchronize(self.device)         # (pending kernels may still use the old arena)
-            s.arena = None
-            s.arena = torch.empty(int(s.ws.total * 1.05) + 1024, device=self.device, dtype=torch.float32)
+            need = int(s.ws.total)
+            if not soft:
+                # size the arena for the widest candidate of every cell once, instead of growing it (device sync + GBs of
+                # hipMalloc) whenever a step samples a wider sub-network than any before
+                wide = [max(range(len(c.m_ops)), key=lambda i, c=c: (c.m_ops[i].mid_channels, c.m_ops[i].se_channels))
+                        for c in self.cells]
+                if list(idxs) != wide:
+                    need = max(need, self._sampled_need(name, wide, x0h, need_wgrad, need_dx0))
+                    return self._plan_with_arena(name, idxs, x0h, need_wgrad, need_dx0, need_dbetas, need)
+            self._grow(s, need)
         s.gen += 1
         return s
+
+    def _grow(self, s, need):
+        if s.arena is not None and s.arena.numel() >= need:
+            return
+        if s.arena is not None:
+            torch.cuda.synchronize(self.device)             # (pending kernels may still use the old arena)
+        s.arena = None
+        s.arena = torch.empty(int(need * 1.02) + 1024, device=self.device, dtype=torch.float32)
+
+    def _sampled_need(self, name, wide, x0h, need_wgrad, need_dx0):
+        tmp = '_size_probe'
+        s = self._slot(tmp)
+        s.arena = torch.empty(0, device=self.device)        # (never launched on; only the plan's size is wanted)
+        N, H, W, _ = x0h.shape
+        pd = s.pd
+        pd.ncell, pd.nstage, pd.soft, pd.need_dx0, pd.efree_mask_lo = len(self.cells), len(self.stages), 0, int(need_dx0), 0
+        h, w = H, W
+        for i, cell in enumerate(self.cells):
+            pd.cell[i] = self._template(i, wide[i], N, h, w)
+            pd.cell[i].need_wgrad = int(need_wgrad)
+            h, w = (h - 1) // cell.stride + 1, (w - 1) // cell.stride + 1
+        for k, st in enumerate(self.stages):
+            sg = pd.stage[k]
+            sg.ncell, sg.start_res, sg.betas, sg.dbetas = st.nblocks, st.start_res, st.betas.data_ptr(), None
+        check(self.lib.tfnas_path_plan(s.ctx, C.byref(pd), C.byref(s.ws)), 'tfnas_path_plan')
+        return int(s.ws.total)
+
+    def _plan_with_arena(self, name, idxs, x0h, need_wgrad, need_dx0, need_dbetas, need):
+        self._grow(self._slot(name), need)
+        return self._plan(name, idxs, x0h, need_wgrad, need_dx0, need_dbetas)
 
     # ---- raw calls ----------------------------------------------------------------------------------------------
     def _fwd(self, slots, x0s, wmix, clx, outs, out_lats, streams):

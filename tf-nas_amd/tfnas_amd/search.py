@@ -54,6 +54,13 @@ class SearchState:
         self._pin = self._pin_ev = None
         self._dp_check = None              # (tensor, expected) of the previous step's sampled-architecture check
         self.arena = self.runner = None
+        self._op_span = {}
+        self._mom_bound = None
+        self._msg = self._opt_scratch = self._gnorm = None
+        self._adam_m = self._adam_v = self._adam_bound = None
+        self._adam_t = 0
+        self._need_zero_grad = True
+        self.expose_grads = False          # w_step: also point .grad of the sampled parameters at their arena ranges
         self._op_params = {}
         self._shared = None
         self._graded = []                  # parameters whose .grad was pointed into the arena by the last w-step
@@ -69,7 +76,7 @@ class SearchState:
             self.runner.close()
         self.arena = WeightArena(self.model)
         self.runner = PathRunner(self.model, self.arena)
-        self._op_params = {}
+        self._op_params, self._op_span, self._mom_bound = {}, {}, None
         cell_params = set()
         for c in self.model.cells():
             for op in c.m_ops:
@@ -78,6 +85,164 @@ class SearchState:
         # accumulated in place into zeroed arena views
         self._shared = [p for p in self.weights if id(p) not in cell_params]
         self._shared_spans = _merge_spans([self.arena.slot[id(p)] for p in self._shared])
+
+    # ---- fused optimizer steps (opt_kernels.hip) -------------------------------------------------------------------
+    def _bind_momentum(self, opt_w):
+        """torch's SGD state and the fused kernel share ONE momentum storage: state[p]['momentum_buffer'] becomes a view of
+        the arena's momentum buffer (existing values are copied in), so state_dict() / load_state_dict() / a later switch
+        to opt_w.step() all keep working.  Re-done when load_state_dict replaced the state tensors."""
+        a = self.arena
+        probe = self._shared[0]
+        buf = opt_w.state.get(probe, {}).get('momentum_buffer')
+        off = a.slot[id(probe)][0]
+        if self._mom_bound is opt_w and buf is not None and buf.data_ptr() == a.m.data_ptr() + 4 * off:
+            return
+        with torch.no_grad():
+            for p in a.params:
+                o, n = a.slot[id(p)]
+                view = a.m[o:o + n].view(p.shape)
+                old = opt_w.state.get(p, {}).get('momentum_buffer')
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old)
+                elif old is None:
+                    view.zero_()
+                opt_w.state[p]['momentum_buffer'] = view
+        self._mom_bound = opt_w
+
+    @staticmethod
+    def _fusable_sgd(opt_w):
+        g = opt_w.param_groups
+        return (isinstance(opt_w, torch.optim.SGD) and len(g) == 1 and not g[0].get('nesterov') and not g[0].get('dampening')
+                and not g[0].get('maximize'))
+
+    def op_span(self, ci, idx):
+        key = (ci, idx)
+        sp = self._op_span.get(key)
+        if sp is None:
+            sp = self._op_span[key] = self.arena.span(self.op_params(ci, idx))
+        return sp
+
+    def fused_weight_step(self, opt_w, idx_lists, grad_clip, group=None):
+        """(all-reduce) + clip_grad_norm_ + SGD over the ranges that received a gradient: the shared parameters (stems, head,
+        classifier) and the sampled candidates -- train_search.py:381-385 in two launches (+ one pack launch and one
+        all-reduce when distributed)."""
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        a = self.arena
+        self._bind_momentum(opt_w)
+        spans = list(self._shared_spans)
+        for idxs in idx_lists:
+            spans.extend(self.op_span(ci, idx) for ci, idx in enumerate(idxs))
+        n = len(spans)
+        off = (C.c_uint64 * n)(*[sp[0] for sp in spans])
+        ln = (C.c_uint64 * n)(*[sp[1] for sp in spans])
+        hp = opt_w.param_groups[0]
+        dev = a.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        lib = _lib.lib()
+        g, goff, scale = a.g, None, 1.0
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 or (world == 1 and dist.is_available() and dist.is_initialized() and FORCE_ALLREDUCE_AT_WORLD_1):
+            global ALLREDUCE_CALLS
+            total = sum(sp[1] for sp in spans)
+            if self._msg is None or self._msg.numel() < total:
+                self._msg = torch.empty(int(total * 1.5), device=dev, dtype=torch.float32)
+            pos, packed = 0, []
+            for sp in spans:
+                packed.append(pos)
+                pos += sp[1]
+            goff = (C.c_uint64 * n)(*packed)
+            _lib.check(lib.tfnas_pack_ranges(_lib.ptr(a.g), _lib.ptr(self._msg), n, off, goff, ln, stream), 'tfnas_pack_ranges')
+            self._check_same_architecture(idx_lists, group)
+            dist.all_reduce(self._msg[:total], op=dist.ReduceOp.SUM, group=group)
+            ALLREDUCE_CALLS += 1
+            g, scale = self._msg, 1.0 / world
+        nblk = sum((sp[1] + 8191) // 8192 for sp in spans)
+        if self._opt_scratch is None or self._opt_scratch.numel() < nblk + 8:
+            self._opt_scratch = torch.empty(max(4096, 2 * nblk), device=dev, dtype=torch.float64)
+            self._gnorm = torch.zeros(2, device=dev, dtype=torch.float32)
+        _lib.check(lib.tfnas_sgd_clip_step(_lib.ptr(a.w), _lib.ptr(g), _lib.ptr(a.m), n, off, goff, ln, float(grad_clip),
+                                           float(hp['lr']), float(hp['momentum']), float(hp['weight_decay']), float(scale),
+                                           _lib.ptr(self._opt_scratch), self._opt_scratch.numel(), _lib.ptr(self._gnorm),
+                                           stream), 'tfnas_sgd_clip_step')
+
+    def _check_same_architecture(self, idx_lists, group):
+        """All ranks must have sampled the same sub-network (same message layout): a MAX all-reduce of (h, -h) of the index
+        hash, checked one step later (no host sync on the hot path).  A mismatch otherwise shows up as an RCCL hang or as
+        silently averaged gradients of different candidates."""
+        import torch.distributed as dist
+        if self._dp_check is not None:
+            t, want = self._dp_check
+            got = t.tolist()
+            if got != want:
+                raise RuntimeError('tfnas_amd: ranks sampled different architectures (hash %r vs %r): every rank needs the '
+                                   'same NoiseSource seed and the same staged log_alphas' % (got, want))
+        h = 0
+        for idxs in idx_lists:
+            for v in idxs:
+                h = (h * 9 + int(v) + 1) % 16777213
+        t = torch.tensor([h, -h], device=self.arena.device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        self._dp_check = (t, [h, -h])
+
+    def fused_arch_step(self, opt_a, grad_clip, group=None):
+        """(all-reduce) + clip + Adam + log-softmax projection of all architecture parameters in ONE launch
+        (train_search.py:414-422).  Adam's moments live in two [n, 8] buffers that torch's optimizer state views."""
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        arch = self.arch
+        n = len(arch)
+        dev = arch[0].device
+        hp = opt_a.param_groups[0]
+        if self._adam_m is None:
+            self._adam_m = torch.zeros(n, 8, device=dev, dtype=torch.float32)
+            self._adam_v = torch.zeros(n, 8, device=dev, dtype=torch.float32)
+            self._adam_t = 0
+            self._adam_bound = None
+        probe = opt_a.state.get(arch[0], {}).get('exp_avg')
+        if self._adam_bound is not opt_a or (probe is not None and probe.data_ptr() != self._adam_m.data_ptr()):
+            with torch.no_grad():                        # import whatever state the torch optimizer holds, then view ours
+                t = 0
+                for i, p in enumerate(arch):
+                    st = opt_a.state.get(p, {})
+                    k = p.numel()
+                    if 'exp_avg' in st:
+                        self._adam_m[i, :k].copy_(st['exp_avg'])
+                        self._adam_v[i, :k].copy_(st['exp_avg_sq'])
+                        t = max(t, int(float(st['step'])))
+                    opt_a.state[p]['exp_avg'] = self._adam_m[i, :k]
+                    opt_a.state[p]['exp_avg_sq'] = self._adam_v[i, :k]
+                    if 'step' not in opt_a.state[p]:          # (so that a later torch opt_a.step() finds a complete state)
+                        opt_a.state[p]['step'] = torch.zeros((), dtype=torch.float32, device=dev if hp_fused(opt_a) else 'cpu')
+                self._adam_t = t
+            self._adam_bound = opt_a
+        grads = [p.grad for p in arch]
+        if any(g is None for g in grads):
+            raise RuntimeError('tfnas_amd: every architecture parameter needs a gradient in the architecture step')
+        scale = 1.0
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 or (world == 1 and dist.is_available() and dist.is_initialized() and FORCE_ALLREDUCE_AT_WORLD_1):
+            allreduce_mean_(grads, group)                # 162 floats: one small message
+        self._adam_t += 1
+        lens = (C.c_int32 * n)(*[p.numel() for p in arch])
+        b1, b2 = hp['betas']
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().tfnas_arch_adam_project(
+            n, _lib.ptr_array([p.data for p in arch]), _lib.ptr_array(grads), lens, _lib.ptr(self._adam_m),
+            _lib.ptr(self._adam_v), float(grad_clip), float(hp['lr']), float(b1), float(b2), float(hp['eps']),
+            float(hp['weight_decay']), self._adam_t, scale, None, stream), 'tfnas_arch_adam_project')
+        # (raw-pointer writes bypass autograd's version counters: a_step re-stages the host copy of the log_alphas itself)
+
+    def export_optimizer_state(self, opt_a):
+        """Write the fused Adam step count back into torch's optimizer state (for state_dict() / checkpoints)."""
+        if self._adam_m is None:
+            return
+        for p in self.arch:
+            st = opt_a.state[p]
+            if 'exp_avg' in st:
+                st['step'] = torch.tensor(float(self._adam_t), device=st['exp_avg'].device if hp_fused(opt_a) else 'cpu')
 
     def op_params(self, ci, idx):
         key = (ci, idx)
@@ -171,6 +336,10 @@ class SearchState:
             self._mode = (weights, arch)
 
 
+def hp_fused(opt):
+    return bool(opt.param_groups[0].get('fused'))
+
+
 def _merge_spans(slots, align=64):
     """[(offset, numel)] -> merged [(offset, padded length)] of adjacent arena slots."""
     out = []
@@ -185,6 +354,8 @@ def _merge_spans(slots, align=64):
 
 # one C call per direction for a whole path (path.py) instead of one autograd node per cell; TFNAS_PATHS=0: per-cell route
 USE_PATHS = os.environ.get('TFNAS_PATHS', '1') != '0'
+# clip + SGD / clip + Adam + projection as fused HIP kernels over the arena ranges (opt_kernels.hip); 0: torch.optim
+FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
@@ -363,7 +534,9 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         model.reset_switches()
     for c, ia in zip(cells, idx_a if idx_b is None else idx_b):
         c.last_idx = ia
-    opt_w.zero_grad()
+    if not (FUSED_OPT and state._fusable_sgd(opt_w)) or state._need_zero_grad:
+        opt_w.zero_grad()                   # (750 parameters; the fused route never leaves a stale .grad behind)
+        state._need_zero_grad = False
     state.begin_weight_grads()
     feat = model._stem(x)
     if bi_sampling:
@@ -381,12 +554,18 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
         loss = F.cross_entropy(logits_g, target)
     loss.backward()
-    state.expose_weight_grads([idx_a] if idx_b is None else [idx_a, idx_b])
-    grads = [p.grad for p in state.weights if p.grad is not None]
-    allreduce_mean_(grads, group)
-    if grad_clip > 0:
-        nn.utils.clip_grad_norm_(state.weights, grad_clip)
-    opt_w.step()
+    idx_lists = [idx_a] if idx_b is None else [idx_a, idx_b]
+    if FUSED_OPT and state._fusable_sgd(opt_w):
+        if state.expose_grads:
+            state.expose_weight_grads(idx_lists)
+        state.fused_weight_step(opt_w, idx_lists, grad_clip, group)
+    else:
+        state.expose_weight_grads(idx_lists)
+        grads = [p.grad for p in state.weights if p.grad is not None]
+        allreduce_mean_(grads, group)
+        if grad_clip > 0:
+            nn.utils.clip_grad_norm_(state.weights, grad_clip)
+        opt_w.step()
     state.mark_step(dev)
     return loss.detach(), logits_g.detach()
 
@@ -416,6 +595,20 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     loss = loss_a + loss_l
     opt_a.zero_grad()
     loss.backward()
+    fused = (FUSED_OPT and state.runner is not None and isinstance(opt_a, torch.optim.Adam) and len(opt_a.param_groups) == 1
+             and not opt_a.param_groups[0].get('amsgrad') and not opt_a.param_groups[0].get('maximize'))
+    if fused:
+        if return_grads:                        # (unclipped, but averaged over ranks like the legacy route returns them)
+            allreduce_mean_([p.grad for p in state.arch if p.grad is not None], group)
+            grads = [p.grad.detach().clone() for p in state.arch]
+            state.fused_arch_step(opt_a, grad_clip, None)
+        else:
+            grads = None
+            state.fused_arch_step(opt_a, grad_clip, group)
+        if hasattr(model, 'stem_features'):
+            state.stage_alpha_host()
+        state.mark_step(x.device)
+        return loss_a.detach(), loss_l.detach(), lat.detach(), grads
     allreduce_mean_([p.grad for p in state.arch if p.grad is not None], group)
     # (a snapshot of the 24 unclipped gradients is 24 tiny launches on a launch-bound path: tests only)
     grads = [p.grad.detach().clone() for p in state.arch] if return_grads else None
