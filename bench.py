@@ -145,6 +145,28 @@ def pair_algorithmic(B, elt=4):
                 bytes_alpha=f0_a, bytes_w=f0_w)
 
 
+def width_sweep_configs():
+    """(name, mc_num_dddict) of SURVEY 8(d) C4: e=(2,4), (3,6), (4,8) and the ragged widths fit_mc_num_by_latency gives for
+    target_lat 10 / 15 / 18 ms (three candidates scaled in turn, as tests/test_gpu_network.py::test_width_sweep_matches_oracle)."""
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g
+    from tfnas_amd.elasticity import fit_mc_num_by_latency
+    from tfnas_amd.latency import get_lookup_latency, load_lat_lookup
+    lut = load_lat_lookup('gpu')
+    out = [('e2_e4', g.uniform_mc_num_dddict(2, 4)), ('e3_e6', g.uniform_mc_num_dddict(3, 6)),
+           ('e4_e8', g.uniform_mc_num_dddict(4, 8))]
+    mcmax = g.get_mc_num_dddict(g.make_mc_mask_dddict(), is_max=True)
+    keys = g.make_lat_lookup_key_dddict()
+    for target in (10.0, 15.0, 18.0):
+        mc = g.initial_mc_num_dddict()
+        for op in (1, 7, 4):
+            arch = OrderedDict((st, OrderedDict((b, op) for b in mc[st])) for st in mc)
+            lat = get_lookup_latency(arch, mc, keys, lut)
+            mc, _ = fit_mc_num_by_latency(arch, mc, mcmax, keys, lut, target, list(mc.keys()), -1 if lat > target else 1)
+        out.append(('ragged_target%d' % int(target), mc))
+    return out
+
+
 def dropin_pair(model, opt_w, opt_a, bw, ba, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0):
     """Two iterations of the reference's train_w_arch body (train_search.py:370-426) written the way the reference writes
     them, against the drop-in model: requires_grad toggling over named_parameters, two sequential sampled forwards with
@@ -292,6 +314,32 @@ def run_gpu(args):
         torch.cuda.synchronize()
         dropin = 2.0 * B * nd / (time.perf_counter() - t0)
 
+    # ---- BASELINE configs[3] / SURVEY 8(d) C4: width sweep (uniform expand ratios over the reachable range + the ragged widths
+    # elasticity scaling produces for three latency targets), latency lookup inside every soft forward; a few pairs each
+    sweep = None
+    if world == 1 and args.width_sweep:
+        sweep = []
+        del state, opt_w, opt_a, model
+        torch.cuda.empty_cache()
+        for name, mc in width_sweep_configs():
+            torch.manual_seed(2)
+            m2 = Network(100, mc, load_lat_lookup('gpu')).to(dev)
+            m2.set_temperature(5.0)
+            st2 = search.SearchState(m2)
+            ow2, oa2 = search.make_optimizers(m2)
+            for i in range(3 + 6):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                search.search_iteration_pair(st2, ow2, oa2, (train[(2 * i) % len(train)], train[(2 * i + 1) % len(train)]),
+                                             val[i % len(val)], noise)
+            torch.cuda.synchronize()
+            sweep.append(dict(widths=name, images_per_s=round(2.0 * B * 6 / (time.perf_counter() - t0), 1)))
+            if st2.runner is not None:
+                st2.runner.close()
+            del st2, ow2, oa2, m2
+            torch.cuda.empty_cache()
+
     result = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -339,7 +387,7 @@ def run_gpu(args):
                                   parallelism='dp%d' % world),
                       roofline=roof, w_step_ms=round(w_ms, 3), a_step_ms=round(a_ms, 3),
                       all_images_per_s=round(3.0 * B * world * args.steps / dt, 2),
-                      dropin_images_per_s=None if dropin is None else round(dropin, 2),
+                      dropin_images_per_s=None if dropin is None else round(dropin, 2), width_sweep=sweep,
                       kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
                                           if v[0]})
     if dist.is_initialized():
@@ -453,6 +501,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50, help='timed iteration pairs (SURVEY 8(d): >= 50)')
     ap.add_argument('--warmup', type=int, default=10, help='untimed warm-up pairs (>= 10)')
     ap.add_argument('--no-dropin', action='store_true', help='skip the reference-style drop-in loop timing')
+    ap.add_argument('--no-width-sweep', dest='width_sweep', action='store_false',
+                    help='skip the BASELINE configs[3] width sweep (6 widths x 6 pairs after the timed region)')
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step-half (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)

@@ -41,3 +41,28 @@ def oracle_cell_from(fx):
     cell.load_state_dict(sd)
     cell.set_temperature(float(fx['T']))
     return cell
+
+
+def tiny_masks(seed=0):
+    """mc_mask_dddict with small max widths (ic + 8 / ic + 16 per candidate -- an MBConv only has an expand convolution when
+    mid > in, layers.py:462 --, 3/4 of the extra channels active, in shuffled positions) so that a whole max-width store is
+    ~20 MB; same nesting as tools/config.py."""
+    from collections import OrderedDict
+    import torch
+    from tfnas_amd import geometry as g
+    gen = torch.Generator().manual_seed(seed)
+    d = OrderedDict()
+    for stage, block, ic, oc, s, act, size in g.iter_cells():
+        ops = OrderedDict()
+        for i in range(8):
+            mx = ic + (8 if g.OP_EXPAND[i] == 3 else 16)
+            m = torch.zeros(mx)
+            m[torch.randperm(mx, generator=gen)[:ic + (mx - ic) * 3 // 4]] = 1.0
+            ops[i] = m
+        d.setdefault(stage, OrderedDict())[block] = ops
+    return d
+
+
+def flat_masks(masks):
+    import torch
+    return torch.cat([m for st in masks.values() for blk in st.values() for m in blk.values()]).numpy().astype('uint8')

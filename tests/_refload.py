@@ -82,3 +82,47 @@ class inject_gumbel:
     def __exit__(self, *a):
         import torch.nn.functional as F
         F.gumbel_softmax = self._orig
+
+
+def slice_main_epoch_blocks():
+    """The three inline blocks of train_search.py's ``main()`` epoch loop, as compiled code objects that run in a caller
+    supplied namespace (they are statements, not functions, in the reference):
+      'load'    :165-194  current-width model <- max-width state_dict through the masks
+      'update'  :234-259  max-width state_dict <- trained model
+      'shrink'  :262-307  parse arch, elasticity scaling, L1-norm re-masking  (the body of ``if epoch >= 10``)
+    The namespace must provide: model (with .module), state_dict, mc_mask_dddict, mc_maxnum_dddict, lat_lookup,
+    lat_lookup_key_dddict, args, logging, torch, np, get_op_and_depth_weights, parse_architecture, get_mc_num_dddict,
+    get_lookup_latency, fit_mc_num_by_latency."""
+    src = open(os.path.join(REF, 'train_search.py')).read()
+    tree = ast.parse(src)
+    main = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'main'][0]
+    loop = [n for n in main.body if isinstance(n, ast.For) and getattr(n.target, 'id', '') == 'epoch'][-1]
+    body = loop.body
+
+    def seg(node):
+        return ast.get_source_segment(src, node) or ''
+    i_load = [i for i, n in enumerate(body) if isinstance(n, ast.For) and "'m_ops' not in key" in seg(n)
+              and 'exec(' in seg(n)][0]
+    i_upd = [i for i, n in enumerate(body) if isinstance(n, ast.Assign) and 'state_dict_from_model' in seg(n)][0]
+    i_shr = [i for i, n in enumerate(body) if isinstance(n, ast.If) and 'epoch >= 10' in seg(n.test)][0]
+    blocks = {
+        'load': body[i_load:i_load + 2],                       # the two for-loops (non-m_ops keys, then masks)
+        'update': body[i_upd:i_upd + 3],                       # state_dict_from_model = ...; two for-loops
+        'shrink': body[i_shr].body,
+    }
+    return {k: compile(ast.fix_missing_locations(ast.Module(v, [])), 'train_search_main_' + k, 'exec')
+            for k, v in blocks.items()}
+
+
+class cuda_is_identity:
+    """train_search.py moves index tensors with ``.cuda()``; on the CPU-only build container make that a no-op."""
+
+    def __enter__(self):
+        import torch
+        self._orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        return self
+
+    def __exit__(self, *a):
+        import torch
+        torch.Tensor.cuda = self._orig

@@ -217,6 +217,50 @@ def latency_kat():
     print('latency kat', {k: v for k, v in kat.items() if k != 'fits'})
 
 
+# ---------------------------------------------------------------- 5. one epoch boundary (train_search.py main(), inline code)
+def epoch_fixture():
+    """Runs the reference's own epoch-boundary statements (AST-sliced blocks of main(): load :165-194, update :234-259,
+    shrink/expand + re-mask :262-307) on a small-width supernet and records what they produce."""
+    import copy, logging, types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), 'tf-nas_amd'))
+    import _golden
+    blocks = _refload.slice_main_epoch_blocks()
+    ts = _refload.slice_train_search(('get_lookup_latency', 'fit_mc_num_by_latency', 'bound_clip'))
+    out = {}
+    for case, (mask_seed, target) in enumerate([(0, 12.0), (5, 5.9)]):
+        masks = _golden.tiny_masks(mask_seed)
+        torch.manual_seed(3 + case)
+        full = torch.nn.DataParallel(ref.Network(100, ref.get_mc_num_dddict(masks, is_max=True), lut))
+        store = {k: v.clone() for k, v in full.state_dict().items()}
+        torch.manual_seed(4 + case)
+        model = torch.nn.DataParallel(ref.Network(100, ref.get_mc_num_dddict(masks), lut))
+        ns = dict(model=model, state_dict=store, mc_mask_dddict=masks, torch=torch, np=np, logging=logging,
+                  mc_maxnum_dddict=ref.get_mc_num_dddict(masks, is_max=True), lat_lookup=lut,
+                  lat_lookup_key_dddict=ref.lat_lookup_key_dddict, args=types.SimpleNamespace(target_lat=target),
+                  get_op_and_depth_weights=ref.get_op_and_depth_weights, parse_architecture=ref.parse_architecture,
+                  get_mc_num_dddict=ref.get_mc_num_dddict, get_lookup_latency=ts['get_lookup_latency'],
+                  fit_mc_num_by_latency=ts['fit_mc_num_by_latency'])
+        with _refload.cuda_is_identity():
+            exec(blocks['load'], ns)
+        sd = model.module.state_dict()
+        out['c%d_loaded' % case] = np.stack([probe(v) for v in sd.values()])
+        gen = torch.Generator().manual_seed(9 + case)
+        with torch.no_grad():
+            for p in model.module.parameters():
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+        with _refload.cuda_is_identity():
+            exec(blocks['update'], ns)
+            exec(blocks['shrink'], ns)
+        out['c%d_store' % case] = np.stack([probe(v) for v in store.values()])
+        out['c%d_masks' % case] = _golden.flat_masks(masks)
+        out['c%d_parsed' % case] = np.array([[int(st[-1]), int(b[-1]), op] for st, bl in ns['parsed_arch'].items()
+                                             for b, op in bl.items()])
+        out['c%d_mc' % case] = np.array([v for st in ns['mc_num_dddict'].values() for b in st.values() for v in b.values()])
+        out['c%d_lat' % case] = np.array([ns['before_lat'], ns['after_lat'], target])
+        out['c%d_seeds' % case] = np.array([mask_seed, 3 + case, 4 + case, 9 + case])
+    np.savez_compressed(os.path.join(HERE, 'epoch_boundary.npz'), **out)
+
+
 if __name__ == '__main__':
     gumbel_kat()
     cell_fixtures()
@@ -224,3 +268,4 @@ if __name__ == '__main__':
     latency_kat()
     for fn in sorted(os.listdir(HERE)):
         print(fn, os.path.getsize(os.path.join(HERE, fn)))
+    epoch_fixture()

@@ -1,0 +1,43 @@
+"""Epoch driver on the GPU (tfnas_amd/epoch.py: run_search / search_epoch; train_search.py:155-315): warm-up epoch, an
+architecture epoch whose boundary re-masks widths, and a third epoch that trains the re-specialised (ragged) widths --
+forward AND backward through the HIP path -- from the sliced max-width store."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_epochs_with_width_remasking(tmp_path):
+    from tfnas_amd import epoch as ep, geometry as g
+    from tfnas_amd.latency import load_lat_lookup
+    lut = load_lat_lookup('gpu')
+    gen = torch.Generator().manual_seed(0)
+
+    def queue(n):
+        return lambda e: [(torch.randn(4, 3, 224, 224, generator=gen), torch.randint(0, 100, (4,), generator=gen))
+                          for _ in range(n)]
+    logs = []
+    hist = ep.run_search(str(tmp_path), lut, queue(3), queue(2), epochs=3, warmup_epochs=1, target_lat=12.0,
+                         log=logs.append)
+    assert [h['steps'] for h in hist] == [3, 3, 3]
+    assert all(os.path.exists(os.path.join(tmp_path, 'searched_model_%02d.pth.tar' % e)) for e in range(4))
+    assert 'parsed_arch' not in hist[0] and 'parsed_arch' in hist[1]
+    assert hist[1]['before_lat'] > 12.0 >= hist[1]['after_lat'] - 0.5 and hist[1]['remasked']
+    assert 'val_top1' in hist[2]                                             # epochs - epoch < 5: validation ran
+    sd0, m0 = ep.load_search_checkpoint(str(tmp_path), 1)
+    sd2, m2 = ep.load_search_checkpoint(str(tmp_path), 2)
+    n1, n2 = g.get_mc_num_dddict(m0), g.get_mc_num_dddict(m2)
+    st, blk, op = hist[1]['remasked'][0]
+    assert n1[st][blk][op] != n2[st][blk][op]                                # epoch 2 ran at new widths
+    assert any(v % 4 for s in n2.values() for b in s.values() for v in b.values())      # ... ragged ones
+    key = 'module.%s.%s.m_ops.%d.depth_conv.conv.weight' % (st, blk, op)
+    sd3, _ = ep.load_search_checkpoint(str(tmp_path), 3)
+    idx = torch.nonzero(m2[st][blk][op]).view(-1)
+    assert not torch.equal(sd3[key][idx], sd2[key][idx])                     # the active rows were trained in epoch 2 ...
+    off = torch.nonzero(m2[st][blk][op] == 0).view(-1)
+    assert torch.equal(sd3[key][off], sd2[key][off])                         # ... the masked-out rows were not touched
+    for v in sd3.values():
+        assert torch.isfinite(v).all()

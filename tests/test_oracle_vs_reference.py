@@ -246,3 +246,88 @@ def test_validate_matches_reference_validate(ref, lut):
     p1, p5, pl = search.validate(om, list(zip(xs, ys)), noise=_Fixed(noise))
     assert abs(p1 - o1) < 1e-4 and abs(p5 - o5) < 1e-4 and abs(pl - ol) < 1e-5
     assert 0.0 < p5 <= 100.0
+
+
+def _tiny_masks(seed=0):
+    import _golden
+    return _golden.tiny_masks(seed)
+
+
+def test_epoch_boundary_matches_reference_main_loop_blocks(ref, lut):
+    """slice / scatter / parse / shrink-expand / L1 re-masking of tfnas_amd.epoch vs the reference's own inline code of
+    main() (train_search.py:165-194, 234-259, 262-307; AST-sliced statement blocks executed as they are)."""
+    import copy, logging, types
+    import numpy as np
+    from tfnas_amd import epoch as ep, geometry as g
+    blocks = _refload.slice_main_epoch_blocks()
+    ts = _refload.slice_train_search(('get_lookup_latency', 'fit_mc_num_by_latency', 'bound_clip'))
+    masks = _tiny_masks()
+    torch.manual_seed(3)
+    full = torch.nn.DataParallel(ref.Network(100, ref.get_mc_num_dddict(masks, is_max=True), lut))
+    store_ref = {k: v.clone() for k, v in full.state_dict().items()}
+    store_new = copy.deepcopy(store_ref)
+    masks_ref, masks_new = copy.deepcopy(masks), copy.deepcopy(masks)
+    # --- load
+    torch.manual_seed(4)
+    model_ref = torch.nn.DataParallel(ref.Network(100, ref.get_mc_num_dddict(masks_ref), lut))
+    ns = dict(model=model_ref, state_dict=store_ref, mc_mask_dddict=masks_ref, torch=torch, np=np, logging=logging,
+              mc_maxnum_dddict=ref.get_mc_num_dddict(masks_ref, is_max=True), lat_lookup=lut,
+              lat_lookup_key_dddict=ref.lat_lookup_key_dddict, args=types.SimpleNamespace(target_lat=12.0),
+              get_op_and_depth_weights=ref.get_op_and_depth_weights, parse_architecture=ref.parse_architecture,
+              get_mc_num_dddict=ref.get_mc_num_dddict, get_lookup_latency=ts['get_lookup_latency'],
+              fit_mc_num_by_latency=ts['fit_mc_num_by_latency'])
+    with _refload.cuda_is_identity():
+        exec(blocks['load'], ns)
+    from tfnas_amd.model_search import Network as HipNetwork            # (constructed on CPU: only forward needs a GPU)
+    torch.manual_seed(4)
+    model_new = HipNetwork(100, g.get_mc_num_dddict(masks_new), lut)
+    ep.slice_weights_from_max(model_new, store_new, masks_new)
+    sd_r, sd_n = model_ref.module.state_dict(), model_new.state_dict()
+    assert list(sd_r) == list(sd_n)
+    for k in sd_r:
+        assert torch.equal(sd_r[k], sd_n[k]), k
+    # --- "train": perturb both models identically, make the arch parameters decisive, then update + shrink
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for (k, a), (_, b) in zip(model_ref.module.named_parameters(), model_new.named_parameters()):
+            d = torch.randn(a.shape, generator=gen) * 0.1
+            a.add_(d)
+            b.add_(d)
+    with _refload.cuda_is_identity():
+        exec(blocks['update'], ns)
+        exec(blocks['shrink'], ns)
+    ep.scatter_weights_to_max(store_new, model_new, masks_new)
+    for k in store_ref:
+        assert torch.equal(store_ref[k], store_new[k]), k
+    op_w, depth_w = ep.get_op_and_depth_weights(model_new)
+    parsed = ep.parse_architecture(op_w, depth_w)
+    assert parsed == ns['parsed_arch']
+    mc_new, before, after = ep.shrink_or_expand(parsed, masks_new, g.get_mc_num_dddict(masks_new, is_max=True),
+                                                g.make_lat_lookup_key_dddict(), lut, 12.0)
+    assert mc_new == ns['mc_num_dddict'] and before == ns['before_lat'] and after == ns['after_lat']
+    changed = ep.remask_by_l1(parsed, mc_new, masks_new, store_new)
+    assert changed, 'the scenario must re-mask at least one candidate'
+    for st in masks_ref:
+        for blk in masks_ref[st]:
+            for op in masks_ref[st][blk]:
+                assert torch.equal(masks_ref[st][blk][op], masks_new[st][blk][op]), (st, blk, op)
+
+
+def test_parse_architecture_and_lr_list_match_reference(ref):
+    import numpy as np
+    from tfnas_amd import epoch as ep
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        ops = [rng.rand(8) for _ in range(18)]
+        depths = [rng.rand(n) for n in (2, 3, 4, 4, 4, 1)]
+        assert ep.parse_architecture(ops, depths) == ref.parse_architecture(ops, depths)
+    m = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(m.parameters(), lr=0.025, momentum=0.9)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 100.0)          # train_search.py:104-117
+    want = []
+    for _ in range(100):
+        want.append(sch.get_last_lr()[0])
+        opt.step()
+        sch.step()
+    got = ep.cosine_lr_list(0.025, 100)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-12)

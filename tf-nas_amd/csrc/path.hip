@@ -24,6 +24,11 @@ struct ScratchSet {
     uint64_t dZ, dEh, bsmall, red, part, part_w;
 };
 
+// The weight-gradient kernels of a cell run on the side stream and may finish up to LAG cells after the data-gradient chain
+// has moved on: LAG + 1 scratch sets and LAG + 2 gradient-ring slots keep everything they read alive that long.
+constexpr int LAG = 2;
+constexpr int NSET = LAG + 1, NRING = LAG + 2;
+
 struct PathCtx {
     int device = 0;
     bool planned = false;
@@ -32,8 +37,8 @@ struct PathCtx {
     CellOff co[TFNAS_MAX_CELLS];
     StageOff so[TFNAS_MAX_STAGES];
     int stage_of[TFNAS_MAX_CELLS];
-    ScratchSet set[2];
-    uint64_t ring[3], dxp;
+    ScratchSet set[NSET];
+    uint64_t ring[NRING], dxp;
     TfnasPathWs ws;
     hipStream_t side = nullptr;
     hipEvent_t fork[TFNAS_MAX_CELLS][3];
@@ -145,7 +150,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         mring = w.out > mring ? w.out : mring;
         mdxp = w.dxp > mdxp ? w.dxp : mdxp;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NSET; ++k) {
         ScratchSet& s = c.set[k];
         s.dZ = off; off += up(mdZ);
         s.dEh = off; off += up(mdEh);
@@ -154,7 +159,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         s.part = off; off += up(TFNAS_PART_FLOATS);
         s.part_w = off; off += up(TFNAS_PART_FLOATS);
     }
-    for (int k = 0; k < 3; ++k) { c.ring[k] = off; off += up(mring); }
+    for (int k = 0; k < NRING; ++k) { c.ring[k] = off; off += up(mring); }
     c.dxp = off; off += up(mdxp);
     for (int st = 0; st + 1 < pd.nstage; ++st) { c.so[st].bound = off; off += up(c.so[st].count); }
     c.so[pd.nstage - 1].bound = ~(uint64_t)0;
@@ -321,10 +326,10 @@ struct BwdRun {
     bool side_on;
 };
 
-// before cell i (or the sink step in front of it) reuses scratch set i%2 and ring slot (i+1)%3, the weight-gradient
-// kernels of cell i+2 -- the last ones that read them -- must be done (they run on the side stream, one cell behind)
+// before cell i (or the sink step in front of it) reuses scratch set i % NSET and ring slot (i+1) % NRING, the
+// weight-gradient kernels of cell i + NSET -- the last ones that read them -- must be done (side stream, <= LAG cells behind)
 int wait_wgrads(BwdRun& r, int i) {
-    const int j = i + 2;
+    const int j = i + NSET;
     if (!r.side_on || j >= r.c->pd.ncell || !r.c->pd.cell[j].need_wgrad) return 0;
     return (int)hipStreamWaitEvent(r.s, r.c->wdone[j], 0);
 }
@@ -335,7 +340,7 @@ int bwd_sink(BwdRun& r, int st, int lat_off) {
     const int last = sg.first_cell + sg.ncell - 1;
     TRY(wait_wgrads(r, last));
     const float* dsink = (st + 1 < c.pd.nstage) ? r.arena + c.so[st].bound : r.dout;
-    float* dlast = r.arena + c.ring[(last + 1) % 3];
+    float* dlast = r.arena + c.ring[(last + 1) % NRING];
     const float* bw = r.arena + c.so[st].bw;
     const bool want_lat = c.pd.soft && r.dcell_lat && r.cell_lat;
     if (!sg.dbetas && !want_lat) return launch_scale_copy(dlast, dsink, bw + (sg.nres - 1), c.so[st].count, r.s);
@@ -356,7 +361,7 @@ int bwd_cell(BwdRun& r, int i) {
     const TfnasStage& sg = pd.stage[st];
     const int j = i - sg.first_cell;                     // this cell's input is res_list[j] of its stage
     const CellOff& o = c.co[i];
-    const ScratchSet& ss = c.set[i & 1];
+    const ScratchSet& ss = c.set[i % NSET];
     if (j != sg.ncell - 1) TRY(wait_wgrads(r, i));       // (the stage's last cell waited in bwd_sink)
     CellBwdBufs b;
     b.x = (j == 0) ? stage_input(c, st, r.x0, r.arena) : r.arena + c.co[i - 1].out;
@@ -366,7 +371,7 @@ int bwd_cell(BwdRun& r, int i) {
     b.Pr = r.arena + o.Pr;
     b.fsmall = r.arena + o.fsmall;
     b.stats = reinterpret_cast<const double*>(r.arena + o.stats);
-    b.dout = r.arena + c.ring[(i + 1) % 3];
+    b.dout = r.arena + c.ring[(i + 1) % NRING];
     b.dZ = r.arena + ss.dZ;
     b.dEh = r.arena + ss.dEh;
     b.bsmall = r.arena + ss.bsmall;
@@ -376,7 +381,7 @@ int bwd_cell(BwdRun& r, int i) {
     b.dxp = r.arena + c.dxp;
     b.dwmix = (r.dwmix && pd.soft) ? r.dwmix + (size_t)i * TFNAS_MAX_GROUPS : nullptr;
     // where the input gradient goes: the ring (next cell's dout), the previous stage's boundary buffer, or the caller
-    if (j > 0) b.dx = r.arena + c.ring[i % 3];
+    if (j > 0) b.dx = r.arena + c.ring[i % NRING];
     else if (st > 0) b.dx = r.arena + c.so[st - 1].bound;
     else b.dx = pd.need_dx0 ? r.dx0 : nullptr;
     // the cell's input also feeds the stage's sink when it is a depth choice: fold bw * dsink into the dx epilogue
