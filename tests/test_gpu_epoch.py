@@ -33,11 +33,15 @@ def test_three_epochs_with_width_remasking(tmp_path):
     st, blk, op = hist[1]['remasked'][0]
     assert n1[st][blk][op] != n2[st][blk][op]                                # epoch 2 ran at new widths
     assert any(v % 4 for s in n2.values() for b in s.values() for v in b.values())      # ... ragged ones
-    key = 'module.%s.%s.m_ops.%d.depth_conv.conv.weight' % (st, blk, op)
     sd3, _ = ep.load_search_checkpoint(str(tmp_path), 3)
-    idx = torch.nonzero(m2[st][blk][op]).view(-1)
-    assert not torch.equal(sd3[key][idx], sd2[key][idx])                     # the active rows were trained in epoch 2 ...
-    off = torch.nonzero(m2[st][blk][op] == 0).view(-1)
-    assert torch.equal(sd3[key][off], sd2[key][off])                         # ... the masked-out rows were not touched
+    trained = 0
+    for st_, blocks in m2.items():
+        for blk_, ops in blocks.items():
+            for op_, mask in ops.items():
+                key = 'module.%s.%s.m_ops.%d.depth_conv.conv.weight' % (st_, blk_, op_)
+                on, off = torch.nonzero(mask).view(-1), torch.nonzero(mask == 0).view(-1)
+                assert torch.equal(sd3[key][off], sd2[key][off]), key        # masked-out rows are never touched
+                trained += int(not torch.equal(sd3[key][on], sd2[key][on]))
+    assert 18 <= trained <= 18 * 6                                           # 3 steps x 2 sampled candidates per cell
     for v in sd3.values():
         assert torch.isfinite(v).all()

@@ -133,9 +133,11 @@ def _run_opt(lut, fused, pairs=1, B=8):
                     torch.randint(0, 100, (B,), device='cuda', generator=gen))
         # ONE w-step and ONE alpha-step from identical state: later steps amplify the last-bit differences of the two
         # implementations (a 1e-8 weight difference moves BN statistics and ReLU masks of the next forward)
+        # (alpha-step first: it does not touch the weights, and the w-step depends on the alphas only through the sampled
+        # indices, so both steps start from bit-identical inputs in the two runs)
         b0, ba = batch(), batch()
-        search.w_step(st, b0[0], b0[1], ow, 5.0, noise.exp('cuda'), noise.rand_pos())
         search.a_step(st, ba[0], ba[1], oa, 15.0, 0.1, 5.0, noise.exp('cuda'))
+        search.w_step(st, b0[0], b0[1], ow, 5.0, noise.exp('cuda'), noise.rand_pos())
         torch.cuda.synchronize()
         mom = {k: ow.state[p]['momentum_buffer'].clone() for k, p in m.named_parameters() if p in ow.state}
         if fused:
