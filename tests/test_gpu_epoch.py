@@ -45,3 +45,20 @@ def test_three_epochs_with_width_remasking(tmp_path):
     assert 18 <= trained <= 18 * 6                                           # 3 steps x 2 sampled candidates per cell
     for v in sd3.values():
         assert torch.isfinite(v).all()
+
+
+def test_lut_builder_measures_monotone_plausible_latencies(tmp_path):
+    """tfnas_amd/lut_builder.py on the GPU: a few keys, coarse width step; the table drops into Network and get_lookup_latency."""
+    from tfnas_amd import lut_builder, geometry as g
+    from tfnas_amd.latency import load_lat_lookup, get_lookup_latency
+    keys = [kv for kv in lut_builder.lut_keys() if kv[0].startswith('MBInvertedResBlock_14_112_') or '_7_192_' in kv[0]]
+    lut = lut_builder.build_latency_lookup(step=224, iters=5, keys=keys)
+    assert 0.01 < lut['base'] < 50.0
+    for key, gm in keys:
+        tab = lut[key]
+        assert len(tab) == gm['max_mc'] and all(0.0 < v < 100.0 for v in tab.values())
+        assert tab[gm['max_mc']] > 0.5 * tab[gm['ic'] + 1]          # wider is not dramatically cheaper
+    p = str(tmp_path / 'lut.npz')
+    lut_builder.save_lat_lookup(lut, p)
+    back = load_lat_lookup(p)
+    assert abs(back[keys[0][0]][200] - lut[keys[0][0]][200]) < 1e-12

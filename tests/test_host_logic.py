@@ -109,3 +109,26 @@ def test_host_gumbel_positions_match_the_oracle_cell_by_cell():
         e = torch.empty(18, 8).exponential_(generator=g)
         want = [int(torch.argmax(orc.gumbel_softmax(torch.log_softmax(la[c], -1), 5.0, e[c]))) for c in range(18)]
         assert search.host_gumbel_positions(la, e, 5.0) == want
+
+
+def test_parsing_known_answers_and_lut_builder_key_set(tmp_path):
+    """Derived-network config / MAC / parameter counts (values the reference's model_eval + flops_benchmark give, checked in
+    tests/test_oracle_vs_reference.py) and the LUT builder's key set == the keys of the shipped reference tables."""
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g, parsing, lut_builder
+    from tfnas_amd.latency import load_lat_lookup
+    arch = OrderedDict((st, OrderedDict((b, 1) for b in blocks)) for st, blocks in g.initial_mc_num_dddict().items())
+    cfg = parsing.derived_config(arch, g.initial_mc_num_dddict(), 1000)
+    assert len(cfg['stage3']) == 4 and cfg['stage1'][0]['mid_channels'] == 96 and cfg['classifier']['out_features'] == 1000
+    assert abs(parsing.count_params_in_MB(cfg) - 4.816272) < 1e-6
+    assert abs(parsing.count_macs_in_M(cfg) - 434.813168) < 1e-4
+    lut = load_lat_lookup('gpu')
+    keys = [k for k, _ in lut_builder.lut_keys()]
+    assert len(keys) == 66 and set(keys) == set(lut) - {'base'}
+    for k, gm in lut_builder.lut_keys():
+        assert len(lut[k]) == gm['max_mc']                     # the shipped tables are dense over 1..max as well
+    p = str(tmp_path / 'x.npz')
+    small = OrderedDict([('base', 1.5), (keys[0], OrderedDict((w + 1, 0.1 * w) for w in range(8)))])
+    lut_builder.save_lat_lookup(small, p)
+    back = load_lat_lookup(p)
+    assert back['base'] == 1.5 and back[keys[0]][8] == small[keys[0]][8]

@@ -331,3 +331,40 @@ def test_parse_architecture_and_lr_list_match_reference(ref):
         sch.step()
     got = ep.cosine_lr_list(0.025, 100)
     assert np.allclose(got, want, rtol=1e-9, atol=1e-12)
+
+
+def test_derived_config_flops_and_params_match_reference_model_eval(ref, lut):
+    """tfnas_amd.parsing vs the reference's models/model_eval.Network(...).config, tools/flops_benchmark hooks and
+    tools/utils.count_parameters_in_MB, for random architectures at ragged widths."""
+    import importlib
+    import numpy as np
+    from tfnas_amd import parsing, geometry as g
+    me = importlib.import_module('models.model_eval')
+    fb = importlib.import_module('tools.flops_benchmark')
+    utils = importlib.import_module('tools.utils')
+    rng = np.random.RandomState(1)
+    for trial in range(3):
+        ops = [rng.rand(8) for _ in range(18)]
+        depths = [rng.rand(n) for n in (2, 3, 4, 4, 4, 1)]
+        parsed = ref.parse_architecture(ops, depths)
+        mc = g.initial_mc_num_dddict()
+        for st in mc:
+            for b in mc[st]:
+                for op in mc[st][b]:
+                    mc[st][b][op] = int(mc[st][b][op] * (0.7 + 0.6 * rng.rand()))
+        net = me.Network(1000, parsed, mc, lut, 0.0, 0.0)
+        cfg = parsing.derived_config(parsed, mc, 1000)
+        assert cfg == net.config
+        assert abs(parsing.count_params_in_MB(cfg) - utils.count_parameters_in_MB(net)) < 1e-9
+        m2 = fb.add_flops_counting_methods(net)
+        m2.eval()
+        with torch.no_grad():
+            m2(torch.zeros(1, 3, 224, 224))
+        assert abs(parsing.count_macs_in_M(cfg) - fb.compute_average_flops_cost(m2) / 1e6) < 1e-6
+        x = torch.zeros(1, 3, 224, 224)
+        want = me.Network(1000, parsed, mc, lut, 0.0, 0.0).get_lookup_latency(x)
+        from tfnas_amd.latency import get_lookup_latency
+        assert abs(get_lookup_latency(parsed, mc, g.make_lat_lookup_key_dddict(), lut) - want) < 1e-9
+        # the exported JSON builds the reference's NetworkCfg
+        import json
+        me.NetworkCfg(1000, json.loads(json.dumps(cfg)), None, 0.0, 0.0)
