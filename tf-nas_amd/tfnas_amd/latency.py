@@ -14,7 +14,7 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 
 
 def load_lat_lookup(which='gpu'):
-    if which in ('gpu', 'cpu'):
+    if which in ('gpu', 'cpu', 'mi355x'):      # gpu / cpu: the reference's tables; mi355x: measured here (lut_builder.py)
         path = os.path.join(_DATA, 'latency_%s.npz' % which)
     else:
         path = which
