@@ -482,15 +482,17 @@ def _attach_pmc_traffic(res):
     (profiles/round1_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
     doubled per MI355X_MICROARCH.md's gfx950 correction); null when the profile has no entry for that family."""
     roof = res.get('roofline')
-    path = os.path.join(ROOT, 'profiles', 'round1_pmc_summary.json')
-    if not roof or not os.path.exists(path):
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_summary.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    if not roof or not cands or 'kernel' not in roof:
         return
+    path = os.path.join(ROOT, 'profiles', cands[-1])            # the latest round's PMC passes
     try:
         pmc = json.load(open(path))
         ent = pmc['families'].get(roof['kernel'])
         if ent and pmc.get('batch_per_gpu') == res['config']['batch_per_gpu']:
             roof['traffic'] = ent['hbm_bytes_per_launch']
-            roof['traffic_source'] = 'profiles/round1_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)'
+            roof['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)' % cands[-1]
     except Exception:
         pass
 

@@ -776,12 +776,14 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
 
 static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
     // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split, partial tiles must fit the scratch
-    int splits = cdiv(1024, out_tiles > 0 ? out_tiles : 1);
+    static const int target = getenv("TFNAS_WGRAD_WGS") ? atoi(getenv("TFNAS_WGRAD_WGS")) : 1024;
+    static const int min_rows = getenv("TFNAS_WGRAD_MINROWS") ? atoi(getenv("TFNAS_WGRAD_MINROWS")) : 256;
+    int splits = cdiv(target, out_tiles > 0 ? out_tiles : 1);
     const size_t cap = TFNAS_PART_FLOATS / (out_size > 0 ? out_size : 1);
     if ((size_t)splits > cap) splits = (int)cap;
     if (splits < 1) splits = 1;
     int rps = cdiv(rows, splits);
-    if (rps < 256) rps = 256;
+    if (rps < min_rows) rps = min_rows;
     return ((rps + 15) / 16) * 16;
 }
 
