@@ -8,7 +8,8 @@
  * device pointers.  Each entry point cites the reference code whose arithmetic it replaces.
  *
  * Conventions
- *  - all tensors are fp32, activations are NHWC ("channels_last"): x[n][h][w][c], c fastest;
+ *  - all tensors are fp32 (the four [pixels][M] stream tensors optionally bf16, TfnasCellDesc.stor), activations are NHWC
+ *    ("channels_last"): x[n][h][w][c], c fastest;
  *  - the caller (PyTorch) owns and allocates every buffer, including saved-for-backward tensors and
  *    scratch; sizes come from tfnas_cell_ws();
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
@@ -87,7 +88,10 @@ typedef struct TfnasCellDesc {
     float eps;                /* BatchNorm eps (1e-5)                               [in] */
     int32_t mode;             /* TFNAS_MODE_CELL / _STEM / _HEAD                    [in] */
     int32_t Hi, Wi;           /* stem mode: height / width of the NCHW input image  [in] */
-    int32_t pad0, pad1, pad2;
+    int32_t stor;             /* storage of the [pixels][M] stream tensors E, D, dZ, dEh: 0 = fp32 (the parity mode),
+                                 1 = bf16 (throughput mode: BASELINE configs[1] "bf16"; statistics, accumulation and every
+                                 other tensor stay fp32; tfnas_cell_ws sizes the four buffers accordingly)        [in] */
+    int32_t pad1, pad2;
     TfnasGroup g[TFNAS_MAX_GROUPS];
 } TfnasCellDesc;
 
@@ -119,6 +123,11 @@ typedef struct TfnasCellWs {
 } TfnasCellWs;
 
 int tfnas_abi_version(void);
+
+/* 1 when this build of the library accepts TfnasCellDesc.stor = 1 (bf16 storage of E, D, dZ, dEh).  The product library
+ * libtfnas_hip.so is built without it (the runtime branches cost the fp32 path 2.3 %); libtfnas_hip_bf16.so -- same sources,
+ * same ABI -- with it. */
+int tfnas_has_bf16_storage(void);
 
 /* Destroys the library-owned side streams / events (after synchronising them).  Optional; safe to call more than once. */
 int tfnas_shutdown(void);

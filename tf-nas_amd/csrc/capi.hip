@@ -97,6 +97,14 @@ extern "C" int tfnas_shutdown(void) {
 
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
+extern "C" int tfnas_has_bf16_storage(void) {
+#ifdef TFNAS_NO_BF16
+    return 0;
+#else
+    return 1;
+#endif
+}
+
 extern "C" uint64_t tfnas_sizeof(int which) {
     switch (which) {
         case 0: return sizeof(TfnasGroup);
@@ -122,6 +130,11 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         return TFNAS_EINVAL;
     }
     if (d->mode == TFNAS_MODE_HEAD && d->G != 1) return TFNAS_EINVAL;
+    if (d->stor != 0 && d->stor != 1) return TFNAS_EINVAL;
+#ifdef TFNAS_NO_BF16
+    if (d->stor) return TFNAS_EINVAL;         // this build has the bf16-storage branches compiled out (see Makefile)
+#endif
+    if (d->stor && d->mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;      // bf16 storage: MixedOP cells only (stems / head keep fp32)
     if (d->N < 1 || d->H < 1 || d->W < 1 || d->oc < 4 || (d->oc & 3)) return TFNAS_EINVAL;
     if (d->oc > 1024) return TFNAS_EINVAL;
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
@@ -165,8 +178,10 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     memset(ws, 0, sizeof(*ws));
     const uint64_t P = (uint64_t)d->N * d->H * d->W, Po = (uint64_t)d->N * d->Ho * d->Wo;
     const uint64_t M = d->M, N = d->N, SE = d->SE, G = d->G, oc = d->oc;
-    ws->E = P * M;
-    ws->D = Po * M;
+    // the four stream tensors: elements P*M / Po*M, stored fp32 or bf16 (two per float slot)
+    const uint64_t sdiv = d->stor ? 2 : 1;
+    ws->E = (P * M + sdiv - 1) / sdiv;
+    ws->D = (Po * M + sdiv - 1) / sdiv;
     ws->Pr = G * Po * oc;
     ws->off_pooled = 0;
     ws->off_gate = N * M;
@@ -177,8 +192,8 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_stats3 = 4 * M;
     ws->stats = 4 * M + 2 * G * oc;
     ws->out = Po * oc;
-    ws->dZ = Po * M;
-    ws->dEh = P * M;
+    ws->dZ = (Po * M + sdiv - 1) / sdiv;
+    ws->dEh = (P * M + sdiv - 1) / sdiv;
     ws->off_dgate = 0;
     ws->off_dpooled = N * M;
     ws->off_dgl = 2 * N * M;
@@ -273,7 +288,7 @@ int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBu
     if (fused2) TRY(launch_bn2_pool(d, b.dZ, b.D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
     else TRY(launch_se_bwd_reduce(d, b.dZ, b.D, stats2, dgate, s));             // SE groups: d gate
     // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
-    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)d.N * d.H * d.W * d.M, s));
+    TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)ws.dEh, s));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
     if (d.need_wgrad) {

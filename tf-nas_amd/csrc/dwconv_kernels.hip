@@ -86,7 +86,7 @@ __device__ __forceinline__ void stage_weights(float* wts, const float* __restric
 template <class FAddr, class FXf>
 __device__ __forceinline__ void load_tile2(float* tile, int L0, int L1, int CC, int cq_shift,
                                            const float* __restrict__ src0, const float* __restrict__ src1, FAddr addr,
-                                           FXf xf) {
+                                           FXf xf, int stor) {
     const int CQ = CC >> 2, total = L0 * L1 * CQ;
     const float inv_l1 = 1.f / (float)L1;
     for (int base = 0; base < total; base += 1024) {
@@ -102,8 +102,8 @@ __device__ __forceinline__ void load_tile2(float* tile, int L0, int L1, int CC, 
             const int c = pix[u] - r * L1;
             size_t a = 0;
             ok[u] = idx < total && addr(r, c, cqv[u], a);
-            v0[u] = ok[u] ? ld4_nt(src0 + a) : zero4();
-            v1[u] = ok[u] ? ld4_nt(src1 + a) : zero4();
+            v0[u] = ok[u] ? ldS4_nt(src0, a, stor) : zero4();
+            v1[u] = ok[u] ? ldS4_nt(src1, a, stor) : zero4();
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void load_tile2(float* tile, int L0, int L1, int CC, 
 
 template <class FAddr, class FXf>
 __device__ __forceinline__ void load_tile(float* tile, int L0, int L1, int CC, int cq_shift, const float* __restrict__ src,
-                                          FAddr addr, FXf xf) {
+                                          FAddr addr, FXf xf, int stor) {
     const int CQ = CC >> 2, total = L0 * L1 * CQ;
     const float inv_l1 = 1.f / (float)L1;
     for (int base = 0; base < total; base += 1024) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void load_tile(float* tile, int L0, int L1, int CC, i
             const int c = pix[u] - r * L1;
             size_t a = 0;
             ok[u] = idx < total && addr(r, c, cqv[u], a);
-            v[u] = ok[u] ? ld4_nt(src + a) : zero4();
+            v[u] = ok[u] ? ldS4_nt(src, a, stor) : zero4();
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
                           v[j] = act_f<ACT>((v[j] - c.x) * c.y);
                       }
                       return v;
-                  });
+                  }, d.stor);
         __syncthreads();
         for (int item = tid; item < nstrips * CQ; item += 256) {
             const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
                 for (int j = 0; j < 4; ++j) {
                     const int wo = wo0 + ow0 + j;
                     if (wo < Wo) {
-                        st4_nt(D + ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq, acc[j]);
+                        stS4_nt(D, ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq, acc[j], d.stor);
                         ssum += acc[j];
                         ssq += acc[j] * acc[j];
                     }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                        a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
                        return ho >= 0 && ho < Ho && wo >= 0 && wo < Wo && c0 + 4 * cq < mcp;
                    },
-                   [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd<ACT>(cst2, 4 * cq, v, dv, has_se, g4, dp4); });
+                   [&](f32x4 v, f32x4 dv, int cq) { return bn2_dd<ACT>(cst2, 4 * cq, v, dv, has_se, g4, dp4); }, d.stor);
         if (KQ > 0) {
             const float inv_iw = 1.f / (float)TIW;
             expand_tile<(KQ > 0 ? KQ : 2), 2>(eh_tile, TIH * TIW, CC, x, xb, [&](int p, size_t& a) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                 const int wi = wi0 + iw0 + j;
                 const bool okj = hi < H && wi < W && c0 + 4 * cq < mcp;
                 if (KQ > 0) ev[j] = ld4(eh_tile + (ih * TIW + iw0 + j) * CC + 4 * cq);
-                else ev[j] = okj ? ld4_nt(E + ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq) : zero4();
+                else ev[j] = okj ? ldS4_nt(E, ((size_t)(n * H + hi) * W + wi) * M + off + c0 + 4 * cq, d.stor) : zero4();
             }
             if (S == 1) {
                 // column of output (wi + PAD - kx) relative to ow0 = wi0 + PAD - (K-1):  iw0 + j - kx + K - 1
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                             t1[q] += deh[q];
                             t2[q] += deh[q] * eh;
                         }
-                        st4_nt(dEh + a, deh);
+                        stS4_nt(dEh, a, deh, d.stor);
                     }
                 }
             }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
                           v[j] = act_f<ACT>((v[j] - c.x) * c.y);
                       }
                       return v;
-                  });
+                  }, d.stor);
         __syncthreads();
         for (int item = tid; item < nstrips * CQ; item += 256) {
             const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
                 const int wo = wo0 + ow0 + j;
                 ok[j] = ho < Ho && wo < Wo && c0 + 4 * cq < mcp;
                 const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-                dd[j] = ok[j] ? ld4_nt(dZ + a) : zero4();
-                dv[j] = ok[j] ? ld4_nt(D + a) : zero4();
+                dd[j] = ok[j] ? ldS4_nt(dZ, a, d.stor) : zero4();
+                dv[j] = ok[j] ? ldS4_nt(D, a, d.stor) : zero4();
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) dd[j] = ok[j] ? bn2_dd<ACT>(cst2, 4 * cq, dd[j], dv[j], has_se, g4, dp4) : zero4();

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_fwd(TfnasCellDe
         gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
-            if (p < P && n0 + lc < mcp) st4_nt(E + (size_t)p * M + off + n0 + lc, v);
+            if (p < P && n0 + lc < mcp) stS4_nt(E, (size_t)p * M + off + n0 + lc, v, d.stor);
         });
         acc_colstats<NT>(acc, cs, cq);
     }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellD
         auto fa = [&](int c, int row, int kl) -> f32x4 {
             const int p = rt * 128 + row, k = (cb + c) * 16 + kl;
             if (p >= Po || k >= mcp) return zero4();
-            f32x4 v = ld4(D + (size_t)p * M + off + k);
+            f32x4 v = ldS4(D, (size_t)p * M + off + k, d.stor);
             const float2 c0 = cst[k], c1 = cst[k + 1], c2 = cst[k + 2], c3 = cst[k + 3];
             v.x = act_f<ACT>((v.x - c0.x) * c0.y);
             v.y = act_f<ACT>((v.y - c1.x) * c1.y);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_dgrad(TfnasCel
         gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
-            if (p < Po && n0 + lc < mcp) st4_nt(dZ + (size_t)p * M + off + n0 + lc, v);
+            if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
         });
     }
 }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
     auto fa = [&](int c, int kl, int m) -> f32x4 {
         const int p = r0 + c * 16 + kl, ch = m0 + m;
         if (p >= r1 || ch >= mcp) return zero4();
-        f32x4 v = ld4(D + (size_t)p * M + off + ch);
+        f32x4 v = ldS4(D, (size_t)p * M + off + ch, d.stor);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
         if (has_se) v *= ld4(gate + (size_t)(p / HW) * M + off + ch);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
             const int p = rt * 128 + row, k = k0 + kl;
             if (p >= P) return zero4();
             if (g < 0) return k < ic ? ld4(x + (size_t)p * ic + k) : zero4();
-            return k < d.g[g].mcp ? ld4(dEh + (size_t)p * M + d.g[g].off + k) : zero4();
+            return k < d.g[g].mcp ? ldS4(dEh, (size_t)p * M + d.g[g].off + k, d.stor) : zero4();
         };
         auto fb = [&](int c, int kl, int n) -> f32x4 {
             int g, k0;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
         const int p = r0 + c * 16 + kl, ch = m0 + m;
         if (p >= r1 || ch >= mcp) return zero4();
         const size_t col = (size_t)off + ch;
-        return bn1_de(cb, ld4(dEh + (size_t)p * M + col), ld4(E + (size_t)p * M + col));
+        return bn1_de(cb, ldS4(dEh, (size_t)p * M + col, d.stor), ldS4(E, (size_t)p * M + col, d.stor));
     };
     auto fb = [&](int c, int kl, int n) -> f32x4 {
         const int p = r0 + c * 16 + kl, cc = n0 + n;

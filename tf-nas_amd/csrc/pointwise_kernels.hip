@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
             for (int u = 0; u < 4; ++u) {
                 const int h = hw + 16 * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
-                v[u] = ld4_nt(D + a);
-                z[u] = (MODE == 1) ? ld4_nt(dZ + a) : zero4();
+                v[u] = ldS4_nt(D, a, d.stor);
+                z[u] = (MODE == 1) ? ldS4_nt(dZ, a, d.stor) : zero4();
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
             for (int u = 0; u < 4; ++u) {
                 const int h = hw + 16 * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
-                v[u] = ld4_nt(D + a);
-                z[u] = ld4_nt(dZ + a);
+                v[u] = ldS4_nt(D, a, d.stor);
+                z[u] = ldS4_nt(dZ, a, d.stor);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void k_bn2_bwd(TfnasCellDesc d, const float* _
             for (int u = 0; u < 4; ++u) {
                 const int p = pb + 16 * u < p1 ? pb + 16 * u : pb;
                 const size_t a = (size_t)p * M + off + ch;
-                da[u] = ld4_nt(dZ + a);
-                dv[u] = ld4_nt(D + a);
+                da[u] = ldS4_nt(dZ, a, d.stor);
+                dv[u] = ldS4_nt(D, a, d.stor);
                 if (has_se) {
                     const size_t b = (size_t)(p / HW) * M + off + ch;
                     gt[u] = ld4(gate + b);

@@ -67,6 +67,60 @@ __device__ __forceinline__ f32x4 ld4_nt(const float* p) {
 }
 __device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 #endif
+// ----------------------------------------------------------------------------- bf16 storage of the stream tensors
+// TfnasCellDesc.stor = 1: E, D, dZ, dEh hold bf16 (round-to-nearest-even on store, exact widening on load); `idx` below is an
+// ELEMENT index, `base` the tensor's base pointer (typed float* throughout the library).  stor is wave-uniform: the branch is
+// a scalar one and the fp32 path executes exactly the instructions it did before.
+typedef unsigned tf_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 bf16x4_widen(uint2 u) {
+    f32x4 r;
+    r.x = __uint_as_float(u.x << 16);
+    r.y = __uint_as_float(u.x & 0xffff0000u);
+    r.z = __uint_as_float(u.y << 16);
+    r.w = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;          // (NaN payloads are not preserved; none occur here)
+}
+__device__ __forceinline__ uint2 bf16x4_narrow(f32x4 v) {
+    uint2 r;
+    r.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+    r.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+    return r;
+}
+#ifdef TFNAS_NO_BF16                 /* A/B builds: compile the bf16 branches out */
+#define TFNAS_STOR(s) 0
+#else
+#define TFNAS_STOR(s) (s)
+#endif
+__device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int stor) {
+    if (TFNAS_STOR(stor)) return bf16x4_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx));
+    return ld4(base + idx);
+}
+__device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int stor) {
+    if (TFNAS_STOR(stor)) {
+        const tf_u32x2 u = __builtin_nontemporal_load(
+            reinterpret_cast<const tf_u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx));
+        return bf16x4_widen(make_uint2(u.x, u.y));
+    }
+    return ld4_nt(base + idx);
+}
+__device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int stor) {
+    if (TFNAS_STOR(stor)) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = bf16x4_narrow(v);
+    else st4(base + idx, v);
+}
+__device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int stor) {
+    if (TFNAS_STOR(stor)) {
+        const uint2 n = bf16x4_narrow(v);
+        tf_u32x2 u = {n.x, n.y};
+        __builtin_nontemporal_store(u, reinterpret_cast<tf_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx));
+    } else {
+        st4_nt(base + idx, v);
+    }
+}
+
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x4 splat4(float a) { f32x4 z = {a, a, a, a}; return z; }
 

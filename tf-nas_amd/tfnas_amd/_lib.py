@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtfnas_hip.so')
+LIB_PATH_BF16 = os.path.join(_HERE, 'libtfnas_hip_bf16.so')     # same sources + the bf16-storage mode (csrc/Makefile)
 
 MAX_GROUPS, MAX_SINK, MAX_CELLS = 8, 4, 32
 ACT = {'relu': 0, 'swish': 1}
@@ -26,7 +27,7 @@ class TfnasCellDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
                                           'Ho', 'Wo', 'M', 'SE')]
                 + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
-                   ('pad0', C.c_int32), ('pad1', C.c_int32), ('pad2', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+                   ('stor', C.c_int32), ('pad1', C.c_int32), ('pad2', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
 
 
 class TfnasCellWs(C.Structure):
@@ -58,6 +59,7 @@ _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _PROTOS = {
     'tfnas_abi_version': (C.c_int, []),
+    'tfnas_has_bf16_storage': (C.c_int, []),
     'tfnas_shutdown': (C.c_int, []),
     'tfnas_sizeof': (C.c_uint64, [C.c_int]),
     'tfnas_cell_plan': (C.c_int, [C.POINTER(TfnasCellDesc)]),
@@ -90,18 +92,20 @@ _PROTOS = {
     'tfnas_sink_bwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, _P, _P, C.c_uint64, C.POINTER(_P), _P, _P, _P, _P]),
 }
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Load (once) and return the shared library; raises RuntimeError when it is absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(bf16=False):
+    """Load (once) and return the shared library; raises RuntimeError when it is absent.  ``bf16=True``: the build that also
+    accepts TfnasCellDesc.stor = 1."""
+    l = _libs.get(bool(bf16))
+    if l is None:
+        path = LIB_PATH_BF16 if bf16 else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
                 'tfnas_amd: HIP extension %s is missing -- run `python -c "import __graft_entry__ as g; g.build()"` '
-                '(or `make -C tf-nas_amd/csrc`). There is no CPU/PyTorch fallback for the MixedOP hot path.' % LIB_PATH)
-        l = C.CDLL(LIB_PATH)
+                '(or `make -C tf-nas_amd/csrc`). There is no CPU/PyTorch fallback for the MixedOP hot path.' % path)
+        l = C.CDLL(path)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)        # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
@@ -110,8 +114,10 @@ def lib():
         for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs)):
             if l.tfnas_sizeof(which) != C.sizeof(st):
                 raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
-        _lib = l
-    return _lib
+        if bool(l.tfnas_has_bf16_storage()) != bool(bf16):
+            raise RuntimeError('tfnas_amd: %s was built %s bf16 storage' % (path, 'without' if bf16 else 'with'))
+        _libs[bool(bf16)] = l
+    return l
 
 
 def check(rc, what):
