@@ -95,7 +95,10 @@ def test_error_codes(lib):
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from tfnas_amd import _lib
-    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, '_libs', {})
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    monkeypatch.setattr(_lib, 'LIB_PATH_BF16', str(tmp_path / 'nope16.so'))
     with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
         _lib.lib()
+    with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
+        _lib.lib(bf16=True)
