@@ -133,7 +133,7 @@ int tfnas_has_bf16_storage(void);
 int tfnas_shutdown(void);
 
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs,
- * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs. */
+ * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs, 6 TfnasBnAffine. */
 uint64_t tfnas_sizeof(int which);
 
 /* Fill the [plan] fields of a descriptor from its [in] fields.  Returns TFNAS_E* on bad geometry. */
@@ -168,6 +168,42 @@ int tfnas_mixedop_bwd(const TfnasCellDesc *d, const float *x, const float *wmix,
                       const double *stats, const float *dout,
                       float *dZ, float *dEh, float *bsmall, double *red, float *part, /* then: dx, dxp, dwmix */
                       float *dx, float *dxp, float *dwmix, void *stream);
+
+/* ---- derived-network ("retrain") path: one MBConv block with AFFINE BatchNorm + running statistics + drop-connect ------------
+ * Reference: models/model_eval.py:31-244 (Network / NetworkCfg: a chain of MBInvertedResBlock(affine=True), layers.py:431-561),
+ * tools/utils.py:77-86 (drop_connect), trained by train_eval.py.  Same kernels as the search cells (G must be 1); the affine
+ * transform is folded into the per-channel statistics tables (csrc/bn_affine.hip).
+ * BatchNorm site i: 0 = after the 1x1 expand (stem mode: after the 3x3 image conv; head: after the 1x1 feature-mix conv),
+ * 1 = after the depthwise conv, 2 = after the 1x1 project.  Channels: mc, mc, oc. */
+typedef struct TfnasBnAffine {
+    const float *weight[3], *bias[3];          /* gamma / beta (device); NULL = that site has no affine part          */
+    float *g_weight[3], *g_bias[3];            /* their gradients, written by the backward when non-NULL               */
+    float *running_mean[3], *running_var[3];   /* training: updated with `momentum` (unbiased variance, torch semantics);
+                                                  eval: read instead of the batch statistics; NULL: mean 0 / var 1 / no update */
+    float momentum;                            /* torch default 0.1                                                    */
+    int32_t eval;                              /* 1: normalise with the running statistics (model.eval())              */
+} TfnasBnAffine;
+
+/* out = [drop_scale[n] *] BN3(project(SE(act(BN2(dw(act(BN1(expand(x)))))))) [+ x]   with affine BatchNorms.
+ * drop_scale: device float[N] = floor(keep + U[0,1)) / keep per image (residual blocks in training) or NULL.
+ * Buffers as tfnas_mixedop_fwd (sizes from tfnas_cell_ws); d->G must be 1, wmix is not used. */
+int tfnas_mbconv_fwd(const TfnasCellDesc *d, const TfnasBnAffine *bn, const float *drop_scale, const float *x,
+                     float *E, float *D, float *Pr, float *fsmall, double *stats, float *part, float *out, void *stream);
+
+/* Backward of tfnas_mbconv_fwd: dx, the block's weight gradients (d->need_wgrad, g_* of the group) and the BatchNorm
+ * parameter gradients (bn->g_weight / g_bias).  dout_s: scratch [N*Ho*Wo][oc] floats, only needed with drop_scale.
+ * In eval mode (bn->eval) the backward treats the statistics as constants (no batch-statistics terms). */
+int tfnas_mbconv_bwd(const TfnasCellDesc *d, const TfnasBnAffine *bn, const float *drop_scale, const float *x,
+                     const float *E, const float *D, const float *Pr, const float *fsmall, const double *stats,
+                     const float *dout, float *dout_s, float *dZ, float *dEh, float *bsmall, double *red, float *part,
+                     float *dx, float *dxp, void *stream);
+
+/* Head with affine BatchNorm (feature_mix_layer of model_eval.py:98 + global pool): site 0 of `bn`. */
+int tfnas_head_affine_fwd(const TfnasCellDesc *d, const TfnasBnAffine *bn, const float *x, float *E, double *stats,
+                          float *part, float *pooled, void *stream);
+int tfnas_head_affine_bwd(const TfnasCellDesc *d, const TfnasBnAffine *bn, const float *x, const float *E,
+                          const double *stats, const float *dpooled, float *dEh, float *cb1, double *red, float *part,
+                          float *dx, float *dxp, void *stream);
 
 /* Network head (mode TFNAS_MODE_HEAD): pooled[N][mc] = mean over pixels of act(BN(x W_expand^T)).
  * Replaces feature_mix_layer (ConvLayer 1x1 + BN + swish) + AdaptiveAvgPool2d(1), models/model_search.py:299-300.

@@ -376,6 +376,106 @@ def validate(model, batches, noises):
     return t1 / n_all, t5 / n_all, tot / n_all, idxs
 
 
+# --------------------------------------------------------------------------- derived ("retrain") network
+class _ConvBN(nn.Module):
+    """conv -> BatchNorm2d(affine, running stats) -> act   (models/layers.py ConvLayer with affine=True, 'weight_bn_act')."""
+
+    def __init__(self, ic, oc, k, stride, act):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(oc)                      # (registered before conv, like BasicLayer: state_dict order)
+        self.conv = nn.Conv2d(ic, oc, k, stride, k // 2, bias=False)
+        self.act = act
+
+    def forward(self, x):
+        return _act(self.bn(self.conv(x)), self.act)
+
+
+class DerivedBlock(nn.Module):
+    """MBInvertedResBlock with affine BatchNorm (models/layers.py:431-561, affine=True) incl. drop-connect on the residual
+    branch (tools/utils.py:77-86).  ``drop_u``: optional injected U[0,1) draws [N] (else torch.rand, like the reference)."""
+
+    def __init__(self, ic, mc, se, oc, k, stride, act):
+        super().__init__()
+        self.in_channels, self.se_channels, self.out_channels = ic, se, oc
+        self.kernel_size, self.stride, self.act_func = k, stride, act
+        self.drop_connect_rate = 0.0
+        self.drop_u = None
+        if mc > ic:
+            self.inverted_bottleneck = _seq(conv=nn.Conv2d(ic, mc, 1, bias=False), bn=nn.BatchNorm2d(mc))
+        else:
+            self.inverted_bottleneck, mc = None, ic
+        self.mid_channels = mc
+        self.depth_conv = _seq(conv=nn.Conv2d(mc, mc, k, stride, k // 2, groups=mc, bias=False), bn=nn.BatchNorm2d(mc))
+        self.squeeze_excite = _seq(conv_reduce=nn.Conv2d(mc, se, 1), conv_expand=nn.Conv2d(se, mc, 1)) if se > 0 else None
+        self.point_linear = _seq(conv=nn.Conv2d(mc, oc, 1, bias=False), bn=nn.BatchNorm2d(oc))
+        self.has_residual = ic == oc and stride == 1
+
+    def forward(self, x):
+        res = x
+        if self.inverted_bottleneck is not None:
+            x = _act(self.inverted_bottleneck.bn(self.inverted_bottleneck.conv(x)), self.act_func)
+        x = _act(self.depth_conv.bn(self.depth_conv.conv(x)), self.act_func)
+        if self.squeeze_excite is not None:
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = self.squeeze_excite.conv_expand(_act(self.squeeze_excite.conv_reduce(s), self.act_func))
+            x = x * torch.sigmoid(s)
+        x = self.point_linear.bn(self.point_linear.conv(x))
+        if self.has_residual:
+            if self.training and self.drop_connect_rate > 0.0:
+                keep = 1.0 - self.drop_connect_rate
+                u = self.drop_u if self.drop_u is not None else torch.rand(x.size(0))
+                x = x.div(keep) * torch.floor(keep + u.view(-1, 1, 1, 1))
+            x = x + res
+        return x
+
+
+class DerivedNetwork(nn.Module):
+    """models/model_eval.Network (:31-131): stems, the chosen candidate of every kept block, feature mix, pool, dropout, FC."""
+
+    def __init__(self, num_classes, parsed_arch, mc_num_dddict, dropout_rate=0.0, drop_connect_rate=0.0):
+        super().__init__()
+        self.dropout_rate = dropout_rate
+        count = 1 + sum(len(parsed_arch[st]) for st in parsed_arch)
+        idx = 1
+        self.first_stem = _ConvBN(3, 32, 3, 2, 'relu')
+        self.second_stem = DerivedBlock(32, 32, 8, 16, 3, 1, 'relu')
+        self.second_stem.drop_connect_rate = drop_connect_rate * idx / count
+        for name, (ics, ocs, ss, act) in STAGE_CFG.items():
+            stage = nn.ModuleList()
+            for i, blk in enumerate(parsed_arch[name]):
+                idx += 1
+                op = parsed_arch[name][blk]
+                b = DerivedBlock(ics[i], mc_num_dddict[name][blk][op], ics[i] * OP_SE_MULT[op], ocs[i], OP_KERNEL[op], ss[i], act)
+                b.drop_connect_rate = drop_connect_rate * idx / count
+                stage.append(b)
+            setattr(self, name, stage)
+        self.feature_mix_layer = _ConvBN(320, 1280, 1, 1, 'swish')
+        self.classifier = _seq(linear=nn.Linear(1280, num_classes))
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)) and m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def blocks(self):
+        return [b for name in STAGE_CFG for b in getattr(self, name)]
+
+    def forward(self, x):
+        x = self.second_stem(self.first_stem(x))
+        for b in self.blocks():
+            x = b(x)
+        x = F.adaptive_avg_pool2d(self.feature_mix_layer(x), 1).flatten(1)
+        if self.dropout_rate > 0.0:
+            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        return self.classifier.linear(x)
+
+
+def label_smooth_loss(logits, target, num_classes, epsilon):
+    """CrossEntropyLabelSmooth (train_eval.py:72-85)."""
+    lp = F.log_softmax(logits, 1)
+    t = torch.zeros_like(lp).scatter_(1, target.unsqueeze(1), 1)
+    t = (1 - epsilon) * t + epsilon / num_classes
+    return (-t * lp).mean(0).sum()
+
+
 def initial_mc_num_dddict(e3=3, e6=6):
     d = OrderedDict()
     for name, (ics, ocs, ss, act) in STAGE_CFG.items():

@@ -1,0 +1,114 @@
+"""Derived-network ("retrain") path on the HIP kernels (tfnas_amd/model_eval.py, tfnas_mbconv_fwd/bwd, csrc/bn_affine.hip) against
+the CPU oracle (oracle.DerivedNetwork, pinned to the reference's models/model_eval.py in tests/test_oracle_vs_reference.py):
+affine BatchNorm incl. parameter gradients and running statistics, train / eval mode, drop-connect, one training step."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+import tfnas_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise(mod, gen):
+    """non-trivial gamma / beta / running statistics (fresh BatchNorms are gamma 1, beta 0, mean 0, var 1)"""
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=gen))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=gen))
+                m.running_var.copy_(1.0 + 0.2 * torch.rand(m.running_var.shape, generator=gen))
+        # a negative gamma as well (the affine fold must not rely on gamma > 0)
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight[0] = -0.7
+                break
+
+
+@pytest.mark.parametrize('geom', [(24, 72, 24, 24, 3, 1, 'relu', 14), (40, 131, 0, 80, 5, 2, 'swish', 13),
+                                  (112, 336, 224, 112, 5, 1, 'swish', 7)])
+@pytest.mark.parametrize('mode', ['train', 'train_drop', 'eval'])
+def test_affine_block_matches_oracle(geom, mode):
+    from tfnas_amd.layers import MBInvertedResBlock
+    ic, mc, se, oc, k, s, act, hw = geom
+    gen = torch.Generator().manual_seed(5)
+    o = orc.DerivedBlock(ic, mc, se, oc, k, s, act)
+    _randomise(o, gen)
+    m = MBInvertedResBlock(ic, mc, se, oc, k, s, affine=True, act_func=act)
+    m.load_state_dict(o.state_dict())
+    m = m.cuda()
+    x = torch.randn(6, ic, hw, hw, generator=gen)
+    ho = (hw - 1) // s + 1
+    r = torch.randn(6, oc, ho, ho, generator=gen)
+    if mode == 'eval':
+        o.eval(); m.eval()
+    else:
+        o.train(); m.train()
+    if mode == 'train_drop':
+        o.drop_connect_rate = m.drop_connect_rate = 0.4
+        u = torch.rand(6, generator=gen)
+        o.drop_u, m.drop_u = u, u
+    xo = x.clone().requires_grad_(True)
+    xm = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yo, ym = o(xo), m(xm)
+    assert torch.allclose(ym.cpu(), yo, atol=2e-5, rtol=1e-4), float((ym.cpu() - yo).abs().max())
+    (yo * r).sum().backward()
+    (ym * r.cuda()).sum().backward()
+    assert torch.allclose(xm.grad.cpu(), xo.grad, atol=2e-5 + 1e-3 * float(xo.grad.abs().max()), rtol=1e-3)
+    for (kk, po), (_, pm) in zip(o.named_parameters(), m.named_parameters()):
+        err, ref = float((pm.grad.cpu() - po.grad).abs().max()), float(po.grad.abs().max())
+        assert err <= 2e-5 + 2e-3 * ref, (kk, err, ref)
+    for (kk, bo), (_, bm) in zip(o.named_buffers(), m.named_buffers()):
+        assert torch.allclose(bm.cpu().float(), bo.float(), atol=1e-5, rtol=1e-4), kk       # running stats / batch counter
+
+
+def _arch():
+    from tfnas_amd import geometry as g
+    arch = OrderedDict((st, OrderedDict((b, (i * 3 + j) % 8) for j, b in enumerate(bl) if j < 2))
+                       for i, (st, bl) in enumerate(g.initial_mc_num_dddict().items()))
+    return arch, g.initial_mc_num_dddict()
+
+
+def test_derived_network_train_step_and_eval_match_oracle():
+    from tfnas_amd import model_eval as me
+    arch, mc = _arch()
+    torch.manual_seed(3)
+    o = orc.DerivedNetwork(50, arch, mc, 0.0, 0.2)
+    _randomise(o, torch.Generator().manual_seed(1))
+    m = me.Network(50, arch, mc, None, 0.0, 0.2)
+    m.load_state_dict(o.state_dict())
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(8, 3, 96, 96, generator=gen)
+    y = torch.randint(0, 50, (8,), generator=gen)
+    for bo, bm in zip([o.second_stem] + o.blocks(), [m.second_stem] + [b for st in m._stages() for b in st]):
+        u = torch.rand(8, generator=gen)
+        bo.drop_u, bm.drop_u = u, u
+    oo = torch.optim.SGD(o.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+    mo = torch.optim.SGD(m.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+    o.train()
+    lo = orc.label_smooth_loss(o(x), y, 50, 0.1)
+    oo.zero_grad(); lo.backward()
+    torch.nn.utils.clip_grad_norm_(o.parameters(), 5.0); oo.step()
+    lm, _ = me.train_step(m, x.cuda(), y.cuda(), me.CrossEntropyLabelSmooth(50, 0.1), mo, 5.0)
+    assert abs(float(lo) - float(lm)) < 1e-4
+    worst = 0.0
+    for (k, a), (_, b) in zip(o.state_dict().items(), m.state_dict().items()):
+        err, ref = float((b.cpu().float() - a.float()).abs().max()), float(a.float().abs().max())
+        assert err <= 1e-5 + 2e-3 * ref, (k, err, ref)
+        worst = max(worst, err)
+    o.eval(); m.eval()
+    with torch.no_grad():
+        eo, em = o(x), m(x.cuda())
+    assert torch.allclose(em.cpu(), eo, atol=1e-3, rtol=1e-3), float((em.cpu() - eo).abs().max())
+    from tfnas_amd import model_eval
+    t1, t5, ls = model_eval.validate(m, [(x, y)])
+    assert 0.0 <= t1 <= t5 <= 100.0 and ls > 0
+    # NetworkCfg from the exported config builds the same network
+    m2 = me.NetworkCfg(50, m.config, None, 0.0, 0.0).cuda()
+    m2.load_state_dict(m.state_dict())
+    m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m2(x.cuda()), em)

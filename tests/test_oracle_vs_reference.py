@@ -368,3 +368,53 @@ def test_derived_config_flops_and_params_match_reference_model_eval(ref, lut):
         # the exported JSON builds the reference's NetworkCfg
         import json
         me.NetworkCfg(1000, json.loads(json.dumps(cfg)), None, 0.0, 0.0)
+
+
+def test_derived_network_oracle_and_product_structure_match_reference_model_eval(ref, lut):
+    """oracle.DerivedNetwork vs the reference's models/model_eval.Network on CPU: same-seed init, train-mode forward /
+    backward with drop-connect + dropout (same torch RNG stream), running statistics, eval-mode forward; and the product's
+    tfnas_amd.model_eval.Network has the identical state_dict / config (its arithmetic is checked on the GPU)."""
+    import importlib
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g, model_eval as mine
+    me = importlib.import_module('models.model_eval')
+    te_smooth = orc.label_smooth_loss
+    arch = OrderedDict((st, OrderedDict((b, (i * 3 + j) % 8) for j, b in enumerate(bl) if j < 2))
+                       for i, (st, bl) in enumerate(g.initial_mc_num_dddict().items()))
+    mc = g.initial_mc_num_dddict()
+    torch.manual_seed(1)
+    r = me.Network(20, arch, mc, lut, 0.2, 0.2)
+    torch.manual_seed(1)
+    o = orc.DerivedNetwork(20, arch, mc, 0.2, 0.2)
+    torch.manual_seed(1)
+    m = mine.Network(20, arch, mc, lut, 0.2, 0.2)
+    assert list(r.state_dict()) == list(o.state_dict()) == list(m.state_dict())
+    for k, v in r.state_dict().items():
+        assert torch.equal(v, o.state_dict()[k]) and torch.equal(v, m.state_dict()[k]), k
+    assert m.config == r.config
+    x = torch.randn(3, 3, 64, 64)
+    y = torch.randint(0, 20, (3,))
+    # (the reference's get_lookup_latency runs the blocks -- in train mode it would move r's running statistics: use a copy)
+    import copy
+    assert abs(m.get_lookup_latency(torch.zeros(1, 3, 224, 224))
+               - copy.deepcopy(r).get_lookup_latency(torch.zeros(1, 3, 224, 224))) < 1e-9
+    outs = []
+    for net in (r, o):
+        net.train()
+        torch.manual_seed(7)                                   # drop-connect / dropout draw from the same stream
+        lg = net(x)
+        loss = te_smooth(lg, y, 20, 0.1)
+        loss.backward()
+        net.eval()
+        with torch.no_grad():
+            le = net(x)
+        outs.append((lg.detach(), le, {k: p.grad.clone() for k, p in net.named_parameters()},
+                     {k: b.clone() for k, b in net.named_buffers()}))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6) and torch.allclose(outs[0][1], outs[1][1], atol=1e-6)
+    for k in outs[0][2]:
+        assert torch.allclose(outs[0][2][k], outs[1][2][k], atol=1e-6, rtol=1e-5), k
+    for k in outs[0][3]:
+        assert torch.allclose(outs[0][3][k].float(), outs[1][3][k].float(), atol=1e-6), k
+    # the reference's loss class == F.cross_entropy(label_smoothing) == the oracle's restatement
+    lg = outs[0][0]
+    assert abs(float(te_smooth(lg, y, 20, 0.1)) - float(mine.CrossEntropyLabelSmooth(20, 0.1)(lg, y))) < 1e-6

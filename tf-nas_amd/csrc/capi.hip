@@ -113,6 +113,7 @@ extern "C" uint64_t tfnas_sizeof(int which) {
         case 3: return sizeof(TfnasStage);
         case 4: return sizeof(TfnasPathDesc);
         case 5: return sizeof(TfnasPathWs);
+        case 6: return sizeof(TfnasBnAffine);
         default: return 0;
     }
 }
@@ -225,19 +226,49 @@ extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && ef
 // ---------------------------------------------------------------------------------------------------------------
 // One cell, forward / backward: the launch sequences shared by the per-cell entry points below and by the path level
 // (path.hip).
-int cell_fwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s) {
+// BatchNorm channel counts / element counts of the three sites of a G = 1 block
+static void bn_site(const TfnasCellDesc& d, int site, int& nch, uint64_t& cnt) {
+    const uint64_t P = (uint64_t)d.N * d.H * d.W, Po = (uint64_t)d.N * d.Ho * d.Wo;
+    nch = site == 2 ? d.oc : d.g[0].mc;
+    cnt = site == 0 ? P : Po;
+}
+static int bn_fwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site, double* stats, hipStream_t s) {
+    int nch;
+    uint64_t cnt;
+    bn_site(d, site, nch, cnt);
+    return launch_bn_fwd_fix(stats, nch, cnt, d.eps, bn->weight[site], bn->bias[site], bn->running_mean[site],
+                             bn->running_var[site], bn->momentum, bn->eval, s);
+}
+
+int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s) {
     double* stats1 = b.stats + ws.off_stats1;
     double* stats2 = b.stats + ws.off_stats2;
     double* stats3 = b.stats + ws.off_stats3;
     float* pooled = b.fsmall + ws.off_pooled;
     float* gate = b.fsmall + ws.off_gate;
     float* hpre = b.fsmall + ws.off_hpre;
+    // affine / eval BatchNorm: the producers run as usual; their statistics tables are rewritten as effective (mean, rstd)
+    // before the consumers -- which then run with eps = -1 (tfnas_dev.h: bn_consts) -- read them
+    const TfnasBnAffine* bn = b.bn;
+    TfnasCellDesc dc = d0;
+    if (bn) dc.eps = -1.f;
+    const TfnasCellDesc& d = dc;
     if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));          // 1x1 expand (all groups) + BN1 statistics
     else TRY(launch_expand_stats_gram(d, b.x, stats1, b.part, s));            // E-free: BN1 statistics from the Gram matrix of x
+    if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
     TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));          // BN1+act fused load, depthwise, BN2 statistics
+    if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));
     TRY(launch_se_pool(d, b.D, stats2, pooled, s));                           // SE squeeze (SE groups only)
     TRY(launch_se_fc_fwd(d, pooled, hpre, gate, b.part, TFNAS_PART_FLOATS, s));    // SE excite (K-split partials in `part`)
     TRY(launch_project_fwd(d, b.D, gate, stats2, b.Pr, stats3, b.part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
+    if (bn) TRY(bn_fwd_fix(d0, bn, 2, stats3, s));
+    if (b.drop_scale && d.has_res) {
+        // drop-connect (tools/utils.py:77-86): out = scale[n] * BN3(.) + x -- the mix kernel without its residual, then one pass
+        TfnasCellDesc dn = dc;
+        dn.has_res = 0;
+        TRY(launch_mix_fwd(dn, b.Pr, stats3, b.wmix, b.x, b.out, s));
+        return launch_rowscale(b.out, b.out, b.x, b.drop_scale, d.N, (uint64_t)d.Ho * d.Wo * d.oc, s);
+    }
     TRY(launch_mix_fwd(d, b.Pr, stats3, b.wmix, b.x, b.out, s));              // sum_g w_g BN3(.) + residual
     return 0;
 }
@@ -250,7 +281,28 @@ static hipStream_t fork_to(const CellSide* so, int k, hipStream_t main) {
     return so->side;
 }
 
-int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBufs& b, hipStream_t s, const CellSide* so) {
+static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site, double* red, hipStream_t s) {
+    int nch;
+    uint64_t cnt;
+    bn_site(d, site, nch, cnt);
+    TRY(launch_bn_bwd_fix(red, nch, cnt, bn->weight[site], bn->bias[site], bn->g_weight[site], bn->g_bias[site], s));
+    // eval mode: the statistics are constants, dx = r_eff * d -- the generic form r*(d - t1 - y*t2) with t1 = t2 = 0
+    if (bn->eval) return (int)hipMemsetAsync(red, 0, sizeof(double) * 2 * (size_t)nch, s);
+    return 0;
+}
+
+int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdBufs& b0, hipStream_t s, const CellSide* so) {
+    const TfnasBnAffine* bn = b0.bn;
+    TfnasCellDesc dc = d0;
+    if (bn) dc.eps = -1.f;
+    const TfnasCellDesc& d = dc;
+    CellBwdBufs b = b0;
+    const float* dout_res = b0.dout;                       // the residual branch sees the unscaled gradient
+    if (b0.drop_scale && d.has_res) {
+        if (!b0.dout_s) return TFNAS_ENULL;
+        TRY(launch_rowscale(b0.dout_s, b0.dout, nullptr, b0.drop_scale, d.N, (uint64_t)d.Ho * d.Wo * d.oc, s));
+        b.dout = b0.dout_s;
+    }
     const double* stats1 = b.stats + ws.off_stats1;
     const double* stats2 = b.stats + ws.off_stats2;
     const double* stats3 = b.stats + ws.off_stats3;
@@ -277,6 +329,7 @@ int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBu
     }
     TRY(launch_mix_bwd_stats(d, b.dout, b.Pr, stats3, b.x, red3, part, s));           // BN3 backward sums (+ d wmix)
     if (b.dwmix) TRY(launch_mix_dw(d, red3, b.red + ws.off_resdot, b.dwmix, s));
+    if (bn) TRY(bn_bwd_fix(d0, bn, 2, red3, s));
     // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
     // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
     if (!b.dx && !d.need_wgrad) return 0;
@@ -291,6 +344,7 @@ int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBu
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)ws.dEh, s));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
+    if (bn) TRY(bn_bwd_fix(d0, bn, 1, red2, s));
     if (d.need_wgrad) {
         // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
         // host-bound w-step; cells without SE launch nothing for it)
@@ -299,13 +353,20 @@ int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBu
         TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
-    TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
+    if (bn) {
+        // (unfused: the reduction that also builds cb1 would use the sums before the affine fix)
+        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, nullptr));
+        TRY(bn_bwd_fix(d0, bn, 0, red1, s));
+        TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
+    } else {
+        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
+    }
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
     if (b.dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
         float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
         TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
-        TRY(launch_expand_dgrad(d, b.dEh, b.x, cb1, gram, b.dout, b.wmix, b.dx, b.dxp, s, b.add_src, b.add_scale));
+        TRY(launch_expand_dgrad(d, b.dEh, b.x, cb1, gram, dout_res, b.wmix, b.dx, b.dxp, s, b.add_src, b.add_scale));
     }
     return 0;
 }
@@ -348,6 +409,86 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
                      dx, dxp, dwmix, nullptr, nullptr};
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
     return guard.join();
+}
+
+extern "C" int tfnas_mbconv_fwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn, const float* drop_scale, const float* x,
+                                float* E, float* D, float* Pr, float* fsmall, double* stats, float* part, float* out,
+                                void* stream) {
+    if (!dp || !bn || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    TfnasCellWs ws;
+    TRY(tfnas_cell_ws(dp, &ws));
+    CellFwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, part, out};
+    b.bn = bn;
+    b.drop_scale = drop_scale;
+    return cell_fwd_impl(d, ws, b, S(stream));
+}
+
+extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn, const float* drop_scale, const float* x,
+                                const float* E, const float* D, const float* Pr, const float* fsmall, const double* stats,
+                                const float* dout, float* dout_s, float* dZ, float* dEh, float* bsmall, double* red,
+                                float* part, float* dx, float* dxp, void* stream) {
+    if (!dp || !bn || !x || !E || !D || !Pr || !fsmall || !stats || !dout || !dZ || !dEh || !bsmall || !red || !part)
+        return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    TfnasCellWs ws;
+    TRY(tfnas_cell_ws(dp, &ws));
+    hipStream_t s = S(stream);
+    SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
+    SideJoinGuard guard;
+    guard.c = sc;
+    guard.main = s;
+    CellSide so = {};
+    if (sc) {
+        so.side = sc->side;
+        for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
+    }
+    CellBwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_FLOATS,
+                     dx, dxp, nullptr, nullptr, nullptr};
+    b.bn = bn;
+    b.drop_scale = drop_scale;
+    b.dout_s = dout_s;
+    TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
+    return guard.join();
+}
+
+extern "C" int tfnas_head_affine_fwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn, const float* x, float* E, double* stats,
+                                     float* part, float* pooled, void* stream) {
+    if (!dp || !bn || !x || !E || !stats || !part || !pooled) return TFNAS_ENULL;
+    const TfnasCellDesc& d0 = *dp;
+    if (d0.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    hipStream_t s = S(stream);
+    TfnasCellDesc d = d0;
+    d.eps = -1.f;
+    TRY(launch_expand_fwd(d, x, E, stats, part, s));
+    TRY(launch_bn_fwd_fix(stats, d0.g[0].mc, (uint64_t)d0.N * d0.H * d0.W, d0.eps, bn->weight[0], bn->bias[0],
+                          bn->running_mean[0], bn->running_var[0], bn->momentum, bn->eval, s));
+    TRY(launch_head_pool(d, E, stats, pooled, s));
+    return 0;
+}
+
+extern "C" int tfnas_head_affine_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn, const float* x, const float* E,
+                                     const double* stats, const float* dpooled, float* dEh, float* cb1, double* red,
+                                     float* part, float* dx, float* dxp, void* stream) {
+    if (!dp || !bn || !x || !E || !stats || !dpooled || !dEh || !cb1 || !red || !part || !dx) return TFNAS_ENULL;
+    const TfnasCellDesc& d0 = *dp;
+    if (d0.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (d0.need_wgrad && !d0.g[0].g_expand) return TFNAS_ENULL;
+    hipStream_t s = S(stream);
+    TfnasCellDesc d = d0;
+    d.eps = -1.f;
+    const uint64_t cnt = (uint64_t)d0.N * d0.H * d0.W;
+    TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));
+    TRY(launch_bn_bwd_fix(red, d0.g[0].mc, cnt, bn->weight[0], bn->bias[0], bn->g_weight[0], bn->g_bias[0], s));
+    if (bn->eval) HIP_TRY(hipMemsetAsync(red, 0, sizeof(double) * 2 * (size_t)d0.g[0].mc, s));
+    TRY(launch_bn1_consts(d, stats, red, cb1, s));
+    float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
+    TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
+    TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, nullptr, nullptr, dx, dxp, s));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
+    return 0;
 }
 
 extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E, double* stats, float* part,

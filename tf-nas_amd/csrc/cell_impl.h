@@ -10,6 +10,8 @@ struct CellFwdBufs {
     double* stats;
     float* part;
     float* out;
+    const TfnasBnAffine* bn = nullptr;   // derived-network path: affine BatchNorm / running statistics (bn_affine.hip)
+    const float* drop_scale = nullptr;   // per-image drop-connect factor (residual blocks, training)
 };
 
 struct CellBwdBufs {
@@ -22,6 +24,9 @@ struct CellBwdBufs {
     float *dx, *dxp, *dwmix;
     const float* add_src;        // optional extra addend of dx: dx += add_scale[0] * add_src  (sink-connecting gradient,
     const float* add_scale;      //   same shape as dx; models/model_search.py:202-204 backward)
+    const TfnasBnAffine* bn = nullptr;
+    const float* drop_scale = nullptr;
+    float* dout_s = nullptr;     // scratch for drop_scale[n] * dout
 };
 
 // where the weight-gradient kernels of a cell go: `side` == nullptr -> the caller's stream

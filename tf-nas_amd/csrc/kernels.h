@@ -98,3 +98,11 @@ int launch_sgd_clip_step(float* w, float* g, float* m, int nranges, const uint64
 int launch_arch_adam_project(int n, float* const* p, const float* const* g, const int32_t* len, float* m, float* v,
                              float max_norm, float lr, float b1, float b2, float eps, float wd, int step, float grad_scale,
                              float* norm_out, hipStream_t s);
+
+// bn_affine.hip (derived-network path: affine BatchNorm folded into the statistics tables, drop-connect)
+int launch_bn_fwd_fix(double* stats, int nch, uint64_t cnt, float eps, const float* gamma, const float* beta, float* rmean,
+                      float* rvar, float momentum, int eval, hipStream_t s);
+int launch_bn_bwd_fix(double* red, int nch, uint64_t cnt, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                      hipStream_t s);
+int launch_rowscale(float* out, const float* y, const float* res, const float* scale, int N, uint64_t per_image,
+                    hipStream_t s);

@@ -48,7 +48,10 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf
 // ----------------------------------------------------------------------------- batch-norm constants
 // stats layout: [channel][2] doubles = (sum, sum of squares) over `cnt` elements.
 // BN of the search net: (x-mean)/sqrt(var_biased+eps), no affine (layers.py:469,498,533).
+// eps < 0: the table already holds the EFFECTIVE (mean, rstd) of an affine / eval-mode BatchNorm, written by k_bn_fwd_fix
+// (bn_affine.hip): gamma*(x-mu)*rho + beta == (x - mean_eff) * rstd_eff with rstd_eff = gamma*rho, mean_eff = mu - beta/rstd_eff.
 __device__ __forceinline__ float2 bn_consts(const double* st, double inv_cnt, float eps) {
+    if (eps < 0.f) return make_float2((float)st[0], (float)st[1]);
     double m = st[0] * inv_cnt;
     double v = st[1] * inv_cnt - m * m;
     if (v < 0.0) v = 0.0;

@@ -55,6 +55,11 @@ class TfnasPathWs(C.Structure):
                 + [(n, C.c_int32) for n in ('out_h', 'out_w', 'out_c', 'pad')])
 
 
+class TfnasBnAffine(C.Structure):
+    _fields_ = ([(n, C.c_void_p * 3) for n in ('weight', 'bias', 'g_weight', 'g_bias', 'running_mean', 'running_var')]
+                + [('momentum', C.c_float), ('eval', C.c_int32)])
+
+
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _PROTOS = {
@@ -66,6 +71,10 @@ _PROTOS = {
     'tfnas_cell_ws': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasCellWs)]),
     'tfnas_mixedop_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 10),
     'tfnas_mixedop_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 17),
+    'tfnas_mbconv_fwd': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasBnAffine)] + [_P] * 10),
+    'tfnas_mbconv_bwd': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasBnAffine)] + [_P] * 17),
+    'tfnas_head_affine_fwd': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasBnAffine)] + [_P] * 6),
+    'tfnas_head_affine_bwd': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasBnAffine)] + [_P] * 11),
     'tfnas_head_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
     'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
     'tfnas_path_create': (C.c_int, [C.POINTER(C.c_void_p)]),
@@ -111,7 +120,7 @@ def lib(bf16=False):
             fn.restype, fn.argtypes = res, args
         if l.tfnas_abi_version() != 1:
             raise RuntimeError('tfnas_amd: ABI version mismatch')
-        for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs)):
+        for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs, TfnasBnAffine)):
             if l.tfnas_sizeof(which) != C.sizeof(st):
                 raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
         if bool(l.tfnas_has_bf16_storage()) != bool(bf16):

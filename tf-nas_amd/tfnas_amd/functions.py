@@ -386,3 +386,142 @@ class SinkFn(torch.autograd.Function):
                                             ptr_array(dres), ptr(dbetas), ptr(dcl), ptr(dots), _stream(dev)),
                   'tfnas_sink_bwd')
         return (dbetas, dcl) + tuple(r.permute(0, 3, 1, 2) for r in dres)
+
+
+# ======================================================================================================================
+# Derived-network ("retrain") path: blocks with AFFINE BatchNorm + running statistics + drop-connect
+# (models/model_eval.py, models/layers.py with affine=True, tools/utils.py:77-86) on the same kernels -- tfnas_mbconv_fwd/bwd.
+def _bn_struct(bns, training, grads=None):
+    """TfnasBnAffine for up to three nn.BatchNorm2d modules (None entries: site without affine)."""
+    a = _lib.TfnasBnAffine()
+    mom = 0.1
+    for i, bn in enumerate(bns):
+        if bn is None:
+            continue
+        a.weight[i], a.bias[i] = bn.weight.data_ptr(), bn.bias.data_ptr()
+        a.running_mean[i], a.running_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        if grads is not None:
+            a.g_weight[i], a.g_bias[i] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
+        mom = 0.1 if bn.momentum is None else bn.momentum
+    a.momentum = mom
+    a.eval = int(not training)
+    return a
+
+
+class MBConvAffineFn(torch.autograd.Function):
+    """One MBInvertedResBlock of the derived network (or the stem cell: plan.mode == MODE_STEM) with affine BatchNorm.
+    inputs: plan, x, drop_scale [N] or None, bns (three nn.BatchNorm2d), training flag, n_conv, *params where
+    params = conv weights (hip_params order) followed by (gamma1, beta1, gamma2, beta2, gamma3, beta3)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, drop_scale, bns, training, n_conv, *params):
+        _require_cuda(x, 'block input')
+        stem = plan.mode == _lib.MODE_STEM
+        xh = x.contiguous() if stem else _nhwc(x)
+        if stem:
+            N, _, H, W = xh.shape
+        else:
+            N, H, W, _ = xh.shape
+        conv = params[:n_conv]
+        d, ws = plan.desc(N, H, W)
+        plan.bind(d, conv)
+        dev = xh.device
+        _same_device(dev, list(params) + [drop_scale], 'a block parameter')
+        E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+        D = torch.empty(ws.D, device=dev, dtype=torch.float32)
+        Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
+        fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
+        stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
+        bn = _bn_struct(bns, training)
+        ds = None if drop_scale is None else drop_scale.contiguous().float()
+        with _on(dev):
+            check(_lib.lib().tfnas_mbconv_fwd(C.byref(d), C.byref(bn), ptr(ds), ptr(xh), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                              ptr(stats), ptr(part), ptr(out), _stream(dev)), 'tfnas_mbconv_fwd')
+        if training:
+            for m in bns:
+                if m is not None and m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
+        ctx.plan, ctx.shape, ctx.bns, ctx.training, ctx.n_conv = plan, (N, H, W), bns, training, n_conv
+        ctx.save_for_backward(xh, ds, E, D, Pr, fsmall, stats, *params)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xh, ds, E, D, Pr, fsmall, stats, *params = ctx.saved_tensors
+        plan, n_conv = ctx.plan, ctx.n_conv
+        N, H, W = ctx.shape
+        d, ws = plan.desc(N, H, W)
+        dev = xh.device
+        conv, bnp = params[:n_conv], params[n_conv:]
+        gconv = [torch.empty_like(p) for p in conv]
+        gbn = [torch.zeros_like(p) for p in bnp]
+        plan.bind(d, conv, gconv)
+        douth = _nhwc(dout)
+        want_dx = ctx.needs_input_grad[1] and plan.mode != _lib.MODE_STEM
+        dZ = torch.empty(ws.dZ, device=dev, dtype=torch.float32)
+        dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
+        bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
+        red = torch.empty(ws.red, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part * 2, device=dev, dtype=torch.float32)
+        dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
+        dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
+        dout_s = torch.empty_like(douth) if ds is not None else None
+        bn = _bn_struct(ctx.bns, ctx.training, gbn)
+        with _on(dev):
+            check(_lib.lib().tfnas_mbconv_bwd(C.byref(d), C.byref(bn), ptr(ds), ptr(xh), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                              ptr(stats), ptr(douth), ptr(dout_s), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
+                                              ptr(part), ptr(dx), ptr(dxp), _stream(dev)), 'tfnas_mbconv_bwd')
+        d.need_wgrad = 0
+        return (None, None if dx is None else dx.permute(0, 3, 1, 2), None, None, None, None) + tuple(gconv) + tuple(gbn)
+
+
+class HeadAffineFn(torch.autograd.Function):
+    """feature_mix_layer (1x1 conv + affine BN + swish) + global average pool of the derived network (model_eval.py:98-99,126-128)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, bn_mod, training, w, gamma, beta):
+        _require_cuda(x, 'head input')
+        xh = _nhwc(x)
+        N, H, W, _ = xh.shape
+        d, ws = plan.desc(N, H, W)
+        plan.bind(d, [w])
+        dev = x.device
+        E = torch.empty(ws.E, device=dev, dtype=torch.float32)
+        stats = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        pooled = torch.empty((N, d.g[0].mc), device=dev, dtype=torch.float32)
+        bn = _bn_struct([bn_mod], training)
+        with _on(dev):
+            check(_lib.lib().tfnas_head_affine_fwd(C.byref(d), C.byref(bn), ptr(xh), ptr(E), ptr(stats), ptr(part), ptr(pooled),
+                                                   _stream(dev)), 'tfnas_head_affine_fwd')
+        if training and bn_mod.num_batches_tracked is not None:
+            bn_mod.num_batches_tracked += 1
+        ctx.plan, ctx.shape, ctx.bn_mod, ctx.training = plan, (N, H, W), bn_mod, training
+        ctx.save_for_backward(xh, E, stats, w, gamma, beta)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        xh, E, stats, w, gamma, beta = ctx.saved_tensors
+        plan = ctx.plan
+        N, H, W = ctx.shape
+        d, ws = plan.desc(N, H, W)
+        dev = xh.device
+        gw = torch.empty_like(w)
+        gbn = [torch.zeros_like(gamma), torch.zeros_like(beta)]
+        plan.bind(d, [w], [gw])
+        dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
+        cb1 = torch.empty(4 * d.M, device=dev, dtype=torch.float32)
+        red = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
+        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
+        dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32)
+        bn = _bn_struct([ctx.bn_mod], ctx.training, gbn)
+        with _on(dev):
+            check(_lib.lib().tfnas_head_affine_bwd(C.byref(d), C.byref(bn), ptr(xh), ptr(E), ptr(stats),
+                                                   ptr(dpooled.contiguous()), ptr(dEh), ptr(cb1), ptr(red), ptr(part), ptr(dx),
+                                                   ptr(dxp), _stream(dev)), 'tfnas_head_affine_bwd')
+        d.need_wgrad = 0
+        return None, dx.permute(0, 3, 1, 2), None, None, gw, gbn[0], gbn[1]

@@ -53,10 +53,11 @@ class ConvLayer(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, affine=False, act_func='relu'):
         super().__init__()
-        if affine:
-            raise NotImplementedError('search-net layers are affine=False (model_search.py:219-275)')
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.act_func = kernel_size, stride, act_func
+        self.affine = affine
+        if affine:           # derived network (models/model_eval.py): BatchNorm2d(affine, running stats); registered before
+            self.bn = nn.BatchNorm2d(out_channels, affine=True, track_running_stats=True)      # conv, like BasicLayer
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, get_same_padding(kernel_size),
                               bias=False)
 
@@ -105,27 +106,28 @@ class MBInvertedResBlock(nn.Module):
     def __init__(self, in_channels, mid_channels, se_channels, out_channels, kernel_size=3, stride=1,
                  affine=False, act_func='relu'):
         super().__init__()
-        if affine:
-            raise NotImplementedError('search-net blocks are affine=False')
         self.in_channels, self.mid_channels = in_channels, mid_channels
         self.se_channels, self.out_channels = se_channels, out_channels
         self.kernel_size, self.stride, self.act_func = kernel_size, stride, act_func
         self.affine = affine
         self.drop_connect_rate = 0.0
+        def bn(ch):          # affine=True: the derived network's BatchNorm2d(affine, running statistics), layers.py:468,497,533
+            return dict(bn=nn.BatchNorm2d(ch, affine=True, track_running_stats=True)) if affine else {}
         if mid_channels > in_channels:
-            self.inverted_bottleneck = _seq(conv=nn.Conv2d(in_channels, mid_channels, 1, 1, 0, bias=False))
+            self.inverted_bottleneck = _seq(conv=nn.Conv2d(in_channels, mid_channels, 1, 1, 0, bias=False), **bn(mid_channels))
         else:
             self.inverted_bottleneck = None
             self.mid_channels = mid_channels = in_channels
         self.depth_conv = _seq(conv=nn.Conv2d(mid_channels, mid_channels, kernel_size, stride,
-                                              get_same_padding(kernel_size), groups=mid_channels, bias=False))
+                                              get_same_padding(kernel_size), groups=mid_channels, bias=False),
+                               **bn(mid_channels))
         if se_channels > 0:
             self.squeeze_excite = _seq(conv_reduce=nn.Conv2d(mid_channels, se_channels, 1, 1, 0, bias=True),
                                        conv_expand=nn.Conv2d(se_channels, mid_channels, 1, 1, 0, bias=True))
         else:
             self.squeeze_excite = None
             self.se_channels = 0
-        self.point_linear = _seq(conv=nn.Conv2d(mid_channels, out_channels, 1, 1, 0, bias=False))
+        self.point_linear = _seq(conv=nn.Conv2d(mid_channels, out_channels, 1, 1, 0, bias=False), **bn(out_channels))
         self.has_residual = (in_channels == out_channels) and (stride == 1)
         self._plan = None
 
@@ -156,4 +158,24 @@ class MBInvertedResBlock(nn.Module):
             return self._stem_forward(x)
         if self._plan is None:
             self._plan = CellPlan(self.in_channels, self.out_channels, self.stride, self.act_func, [self])
+        if self.affine:
+            return self._affine_forward(x)
         return MixedOpFn.apply(self._plan, x, None, *self.hip_params())
+
+    def bn_modules(self):
+        return [self.inverted_bottleneck.bn, self.depth_conv.bn, self.point_linear.bn]
+
+    def _affine_forward(self, x):
+        """Derived-network block (layers.py:539-561 with affine BatchNorm; drop_connect of tools/utils.py:77-86 on the residual
+        branch in training) -- tfnas_mbconv_fwd/bwd."""
+        from .functions import MBConvAffineFn
+        ds = None
+        if self.training and self.has_residual and self.drop_connect_rate > 0.0:
+            keep = 1.0 - self.drop_connect_rate
+            u = getattr(self, 'drop_u', None)                   # (tests inject the uniform draws)
+            u = torch.rand(x.size(0), dtype=x.dtype, device=x.device) if u is None else u.to(x.device)
+            ds = torch.floor(keep + u) / keep
+        bns = self.bn_modules()
+        conv = self.hip_params()
+        bnp = [t for m in bns for t in (m.weight, m.bias)]
+        return MBConvAffineFn.apply(self._plan, x, ds, bns, self.training, len(conv), *conv, *bnp)

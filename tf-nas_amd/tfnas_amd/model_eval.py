@@ -1,0 +1,231 @@
+"""Derived ("searched") network for the retrain path -- drop-in for the reference's ``models/model_eval.py``
+(BASELINE configs[4]).
+
+``Network(num_classes, parsed_arch, mc_num_dddict, lat_lookup, dropout_rate, drop_connect_rate)`` (model_eval.py:31-244) and
+``NetworkCfg(num_classes, model_config, ...)`` (:247-430) with the reference's module / parameter / buffer names (``state_dict``
+keys identical, incl. BatchNorm running statistics), ``forward(x) -> logits``, ``get_lookup_latency(x)`` and ``config``.  Every
+block -- stems, MBConv blocks with AFFINE BatchNorm, running statistics in train / eval mode and drop-connect, the feature-mix
+head -- runs on the HIP kernels of the search path (``tfnas_mbconv_fwd/bwd``, ``tfnas_head_affine_fwd/bwd``: the affine part is
+folded into the per-channel statistics tables, csrc/bn_affine.hip); dropout, the classifier GEMM and the loss are torch ops.
+``CrossEntropyLabelSmooth`` and ``train_step`` / ``validate`` restate train_eval.py:72-85, 228-293.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, geometry
+from .functions import CellPlan, HeadAffineFn, MBConvAffineFn
+from .layers import ConvLayer, LinearLayer, MBInvertedResBlock
+from .parsing import derived_config
+
+
+class _StemBlock:
+    """first_stem.conv + second_stem presented as one candidate block of a TFNAS_MODE_STEM cell."""
+
+    def __init__(self, first, second):
+        self.first, self.second = first, second
+        self.mid_channels, self.kernel_size, self.se_channels = second.mid_channels, second.kernel_size, second.se_channels
+
+    def hip_params(self):
+        se = self.second.squeeze_excite
+        return [self.first.conv.weight, self.second.depth_conv.conv.weight, self.second.point_linear.conv.weight,
+                se.conv_reduce.weight, se.conv_reduce.bias, se.conv_expand.weight, se.conv_expand.bias]
+
+
+class _HeadBlock:
+    def __init__(self, layer):
+        self.layer = layer
+        self.mid_channels, self.kernel_size, self.se_channels = layer.out_channels, 3, 0
+
+    def hip_params(self):
+        return [self.layer.conv.weight]
+
+
+class _DerivedBase(nn.Module):
+    def _finish(self, num_classes):
+        self.feature_mix_layer = ConvLayer(320, 1280, kernel_size=1, stride=1, affine=True, act_func='swish')
+        self.global_avg_pooling = nn.AdaptiveAvgPool2d(1)
+        self.classifier = LinearLayer(1280, num_classes)
+        self._initialization()
+        self._stem_plan = self._head_plan = None
+
+    def _stages(self):
+        return [getattr(self, 'stage%d' % i) for i in range(1, 7)]
+
+    def _stem(self, x):
+        fs, ss = self.first_stem, self.second_stem
+        if self._stem_plan is None:
+            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [_StemBlock(fs, ss)], mode=_lib.MODE_STEM)
+        plan = self._stem_plan
+        bns = [fs.bn, ss.depth_conv.bn, ss.point_linear.bn]
+        conv = plan.params()
+        bnp = [t for m in bns for t in (m.weight, m.bias)]
+        return MBConvAffineFn.apply(plan, x, None, bns, self.training, len(conv), *conv, *bnp)
+
+    def _head(self, x):
+        fm = self.feature_mix_layer
+        if self._head_plan is None:
+            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [_HeadBlock(fm)], mode=_lib.MODE_HEAD)
+        return HeadAffineFn.apply(self._head_plan, x, fm.bn, self.training, fm.conv.weight, fm.bn.weight, fm.bn.bias)
+
+    def forward(self, x):
+        x = self._stem(x)
+        for stage in self._stages():
+            for block in stage:
+                x = block(x)
+        x = self._head(x)                                   # feature_mix_layer + global_avg_pooling, [N, 1280]
+        if self.dropout_rate > 0.0:
+            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        return self.classifier(x)
+
+    def get_lookup_latency(self, x):
+        """Sum of the looked-up block latencies (model_eval.py:133-212); ``x`` only provides the input resolution."""
+        if not self.lat_lookup:
+            return 0.0
+        lat = self.lat_lookup['base']
+        size = (x.size(-1) - 1) // 2 + 1                    # after first_stem (stride 2); second_stem keeps it
+        for stage in self._stages():
+            for b in stage:
+                key = '{}_{}_{}_{}_{}_k{}_s{}_{}'.format(b.name, size, b.in_channels, b.se_channels, b.out_channels,
+                                                         b.kernel_size, b.stride, b.act_func)
+                lat += self.lat_lookup[key][b.mid_channels]
+                size = (size - 1) // b.stride + 1
+        return lat
+
+    @staticmethod
+    def _block_config(b):
+        return {'name': 'MBInvertedResBlock', 'in_channels': b.in_channels, 'mid_channels': b.mid_channels,
+                'se_channels': b.se_channels, 'out_channels': b.out_channels, 'kernel_size': b.kernel_size, 'stride': b.stride,
+                'groups': 1, 'has_shuffle': False, 'bias': False, 'use_bn': True, 'affine': True, 'act_func': b.act_func}
+
+    @property
+    def config(self):
+        from .parsing import _conv_layer_config
+        cfg = {'first_stem': _conv_layer_config(3, 32, 3, 2, 'relu'), 'second_stem': self._block_config(self.second_stem)}
+        for i, stage in enumerate(self._stages(), start=1):
+            cfg['stage%d' % i] = [self._block_config(b) for b in stage]
+        cfg['feature_mix_layer'] = _conv_layer_config(320, 1280, 1, 1, 'swish')
+        cl = self.classifier
+        cfg['classifier'] = {'name': 'LinearLayer', 'in_features': cl.in_features, 'out_features': cl.out_features,
+                             'bias': True, 'use_bn': False, 'affine': False, 'act_func': None, 'ops_order': 'weight_bn_act'}
+        return cfg
+
+    def _initialization(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)) and m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+
+class Network(_DerivedBase):
+    def __init__(self, num_classes, parsed_arch, mc_num_dddict, lat_lookup=None, dropout_rate=0.0, drop_connect_rate=0.0):
+        super().__init__()
+        self.lat_lookup, self.mc_num_dddict, self.parsed_arch = lat_lookup, mc_num_dddict, parsed_arch
+        self.dropout_rate, self.drop_connect_rate = dropout_rate, drop_connect_rate
+        self.block_count = 1 + sum(len(parsed_arch[st]) for st in parsed_arch)
+        self.block_idx = 0
+        self.first_stem = ConvLayer(3, 32, kernel_size=3, stride=2, affine=True, act_func='relu')
+        self.second_stem = MBInvertedResBlock(32, 32, 8, 16, kernel_size=3, stride=1, affine=True, act_func='relu')
+        self.block_idx += 1
+        self.second_stem.drop_connect_rate = self.drop_connect_rate * self.block_idx / self.block_count
+        for name, cfg in geometry.STAGES.items():
+            stage = nn.ModuleList()
+            for i, block_name in enumerate(parsed_arch[name]):
+                self.block_idx += 1
+                op = parsed_arch[name][block_name]
+                ic, oc, s = cfg['ics'][i], cfg['ocs'][i], cfg['ss'][i]
+                blk = MBInvertedResBlock(ic, mc_num_dddict[name][block_name][op], geometry.se_channels(ic, op), oc,
+                                         geometry.OP_KERNEL[op], s, affine=True, act_func=cfg['act'])
+                blk.drop_connect_rate = self.drop_connect_rate * self.block_idx / self.block_count
+                stage.append(blk)
+            setattr(self, name, stage)
+        self._finish(num_classes)
+
+
+class NetworkCfg(_DerivedBase):
+    """Built from the exported ``model.config`` JSON (model_eval.py:247-300; parsing.derived_config writes it)."""
+
+    def __init__(self, num_classes, model_config, lat_lookup=None, dropout_rate=0.0, drop_connect_rate=0.0):
+        super().__init__()
+        self.lat_lookup, self.model_config = lat_lookup, model_config
+        self.dropout_rate, self.drop_connect_rate = dropout_rate, drop_connect_rate
+        self.block_count = 1 + sum(len(v) for k, v in model_config.items() if k.startswith('stage'))
+        self.block_idx = 0
+
+        def mb(c):
+            if c['name'] != 'MBInvertedResBlock' or c.get('groups', 1) != 1 or c.get('has_shuffle') or c.get('bias'):
+                raise NotImplementedError('only plain MBInvertedResBlock configs are supported: %r' % (c,))
+            return MBInvertedResBlock(c['in_channels'], c['mid_channels'], c['se_channels'], c['out_channels'],
+                                      c['kernel_size'], c['stride'], affine=c.get('affine', True), act_func=c['act_func'])
+        fs = model_config['first_stem']
+        self.first_stem = ConvLayer(fs['in_channels'], fs['out_channels'], fs['kernel_size'], fs['stride'], affine=True,
+                                    act_func=fs['act_func'])
+        self.second_stem = mb(model_config['second_stem'])
+        self.block_idx += 1
+        self.second_stem.drop_connect_rate = self.drop_connect_rate * self.block_idx / self.block_count
+        for i in range(1, 7):
+            stage = nn.ModuleList()
+            for c in model_config['stage%d' % i]:
+                self.block_idx += 1
+                blk = mb(c)
+                blk.drop_connect_rate = self.drop_connect_rate * self.block_idx / self.block_count
+                stage.append(blk)
+            setattr(self, 'stage%d' % i, stage)
+        self._finish(num_classes)
+
+
+class CrossEntropyLabelSmooth(nn.Module):
+    """train_eval.py:72-85: mean over the batch of -sum_k ((1-eps) onehot + eps/K) log_softmax."""
+
+    def __init__(self, num_classes, epsilon):
+        super().__init__()
+        self.num_classes, self.epsilon = num_classes, epsilon
+
+    def forward(self, xs, targets):
+        return F.cross_entropy(xs, targets, label_smoothing=self.epsilon)
+
+
+def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None):
+    """One iteration of train_eval.py:228-252 (forward, label-smoothed loss, backward, clip, SGD); with a process group the
+    gradients are averaged with one flat all-reduce before clipping (one process per GPU instead of apex DDP)."""
+    import torch.distributed as dist
+    model.train()
+    logits = model(x)
+    loss = criterion(logits, target)
+    optimizer.zero_grad()
+    loss.backward()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=group)
+        flat.mul_(1.0 / dist.get_world_size(group))
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    if grad_clip > 0:
+        nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+    optimizer.step()
+    return loss.detach(), logits.detach()
+
+
+def validate(model, val_queue, criterion=None):
+    """train_eval.py:271-293: eval mode (running statistics), top-1 / top-5 / loss."""
+    from .search import AverageMeter, accuracy
+    criterion = criterion or F.cross_entropy
+    objs, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    dev = next(model.parameters()).device
+    for x, target in val_queue:
+        x, target = x.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        with torch.no_grad():
+            logits = model(x)
+            loss = criterion(logits, target)
+        p1, p5 = accuracy(logits, target, topk=(1, 5))
+        vals = torch.stack([loss.float(), p1, p5]).tolist()
+        n = x.size(0)
+        objs.update(vals[0], n)
+        top1.update(vals[1], n)
+        top5.update(vals[2], n)
+    return top1.avg, top5.avg, objs.avg
