@@ -479,6 +479,26 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
             g4 = ld4(gate + (size_t)n * M + off + c0 + 4 * mycq);
             dp4 = ld4(dpooled + (size_t)n * M + off + c0 + 4 * mycq) * splat4(inv_hw);
         }
+        // The (dZ, D) operands of this thread's FIRST item of the tile are requested before the E tile is staged: both are
+        // plain global loads with ~2 us of latency at 2 waves per SIMD, and a tile has one item per thread (T0*T1/4 strips x CQ
+        // = 256), so without this the two latencies were paid one after the other for every tile.
+        const int nitems = nstrips * CQ;
+        auto item_ops = [&](int item, f32x4 (&dd)[4], f32x4 (&dv)[4], bool (&ok)[4]) {
+            const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
+            const int oh = st / nsw, ow0 = (st - oh * nsw) * 4;
+            const int ho = ho0 + oh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wo = wo0 + ow0 + j;
+                ok[j] = ho < Ho && wo < Wo && c0 + 4 * cq < mcp;
+                const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
+                dd[j] = ok[j] ? ldS4_nt(dZ, a, d.stor) : zero4();
+                dv[j] = ok[j] ? ldS4_nt(D, a, d.stor) : zero4();
+            }
+        };
+        f32x4 pdd[4], pdv[4];
+        bool pok[4] = {false, false, false, false};
+        if (tid < nitems) item_ops(tid, pdd, pdv, pok);
         __syncthreads();
         load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
                   [&](int r, int c, int cq, size_t& a) {
@@ -495,19 +515,20 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
                       return v;
                   }, d.stor);
         __syncthreads();
-        for (int item = tid; item < nstrips * CQ; item += 256) {
+        for (int item = tid; item < nitems; item += 256) {
             const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
             const int oh = st / nsw, ow0 = (st - oh * nsw) * 4;
-            const int ho = ho0 + oh;
             f32x4 dd[4], dv[4];
             bool ok[4];
+            if (item == tid) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int wo = wo0 + ow0 + j;
-                ok[j] = ho < Ho && wo < Wo && c0 + 4 * cq < mcp;
-                const size_t a = ((size_t)(n * Ho + ho) * Wo + wo) * M + off + c0 + 4 * cq;
-                dd[j] = ok[j] ? ldS4_nt(dZ, a, d.stor) : zero4();
-                dv[j] = ok[j] ? ldS4_nt(D, a, d.stor) : zero4();
+                for (int j = 0; j < 4; ++j) {
+                    dd[j] = pdd[j];
+                    dv[j] = pdv[j];
+                    ok[j] = pok[j];
+                }
+            } else {
+                item_ops(item, dd, dv, ok);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) dd[j] = ok[j] ? bn2_dd<ACT>(cst2, 4 * cq, dd[j], dv[j], has_se, g4, dp4) : zero4();

@@ -66,6 +66,12 @@ class ConvLayer(nn.Module):
         return 'ConvLayer'
 
     def forward(self, x):
+        # Network.forward never comes here (stems and head run as HIP cells, model_search.py / model_eval.py); this body
+        # serves callers that invoke the layer on its own.  Like everything else in the package it has no CPU path.
+        if not x.is_cuda:
+            raise RuntimeError('tfnas_amd: ConvLayer input must live on the GPU (no CPU implementation)')
+        if self.affine:
+            return _act(self.bn(self.conv(x)), self.act_func)
         if self.kernel_size > 1 and self.in_channels <= 4:
             # image stem (3 input channels): im2col + one GEMM; rocBLAS handles this far better than MIOpen's
             # fp32 3-channel wgrad (tools/stem_bench.py: 3.7 ms vs 12.6 ms fwd+wgrad at batch 128)
@@ -144,6 +150,10 @@ class MBInvertedResBlock(nn.Module):
         return ps
 
     def _stem_forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('tfnas_amd: MBInvertedResBlock input must live on the GPU (no CPU implementation)')
+        if self.affine:
+            raise RuntimeError('tfnas_amd: the derived network runs its stem through model_eval.Network._stem')
         res = x
         y = _act(_bn(self.depth_conv.conv(x)), self.act_func)
         if self.squeeze_excite is not None:

@@ -172,22 +172,32 @@ class SearchState:
 
     def _check_same_architecture(self, idx_lists, group):
         """All ranks must have sampled the same sub-network (same message layout): a MAX all-reduce of (h, -h) of the index
-        hash, checked one step later (no host sync on the hot path).  A mismatch otherwise shows up as an RCCL hang or as
-        silently averaged gradients of different candidates."""
+        hash, copied to pinned host memory asynchronously and compared once that copy has completed -- one or two steps
+        later, never blocking the launching thread (a .tolist() here would wait for the whole backward just enqueued).
+        A mismatch otherwise shows up as an RCCL hang or as silently averaged gradients of different candidates."""
         import torch.distributed as dist
-        if self._dp_check is not None:
-            t, want = self._dp_check
-            got = t.tolist()
-            if got != want:
-                raise RuntimeError('tfnas_amd: ranks sampled different architectures (hash %r vs %r): every rank needs the '
-                                   'same NoiseSource seed and the same staged log_alphas' % (got, want))
+        pending = []
+        for host, ev, want in self._dp_check or []:
+            if ev.query():
+                got = host.tolist()
+                if got != want:
+                    raise RuntimeError('tfnas_amd: ranks sampled different architectures (hash %r vs %r): every rank needs '
+                                       'the same NoiseSource seed and the same staged log_alphas' % (got, want))
+            else:
+                pending.append((host, ev, want))
         h = 0
         for idxs in idx_lists:
             for v in idxs:
                 h = (h * 9 + int(v) + 1) % 16777213
-        t = torch.tensor([h, -h], device=self.arena.device, dtype=torch.int32)
+        dev = self.arena.device
+        t = torch.tensor([h, -h], dtype=torch.int32).to(dev, non_blocking=True)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        self._dp_check = (t, [h, -h])
+        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        pending.append((host, ev, [h, -h]))
+        self._dp_check = pending[-4:]
 
     def fused_arch_step(self, opt_a, grad_clip, group=None):
         """(all-reduce) + clip + Adam + log-softmax projection of all architecture parameters in ONE launch

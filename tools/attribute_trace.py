@@ -11,7 +11,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
-marks = [e[0] for e in ev if e[2].startswith('k_arch_project')]
+marks = [e[0] for e in ev if (e[2].startswith('k_arch_project') or e[2].startswith('k_arch_adam_project'))]
 a, b = marks[-1 - npairs], marks[-1]
 seg = [e for e in ev if a <= e[0] < b]
 

@@ -22,7 +22,7 @@ def fam(n):
     return re.sub(r'<.*', '', n)
 
 
-proj = [e[1] for e in ev if e[2].startswith('k_arch_project')]
+proj = [e[1] for e in ev if (e[2].startswith('k_arch_project') or e[2].startswith('k_arch_adam_project'))]
 afwd = [e[0] for e in ev if e[2].startswith('k_arch_fwd')]
 # segments: alpha = [k_arch_fwd start, k_arch_project end]; w = between
 segs = []
