@@ -33,12 +33,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'tf-nas_amd'))
 
-# The w-step keeps four HIP streams busy (two sampled paths x {data-gradient chain, weight-gradient side stream}).  The HIP
-# runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has created its own streams the
-# four compute streams no longer get a queue each and the w-step loses its overlap (24.4 -> 29.5 ms measured).  Must be set
-# before the first HIP call.
-if 'RANK' in os.environ:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# Hardware queues: leave GPU_MAX_HW_QUEUES at its default (4).  Round 1 raised it to 8 under torch.distributed.run; with the
+# path level of round 2 that setting costs 30 % of a pair once the all-reduce runs (108 vs 83 ms, 1 rank, forced all-reduce),
+# and what round 1 was compensating for -- a 25 % slower w-step as soon as RCCL was initialised -- came from EAGER
+# communicator creation (init_process_group(device_id=...)); the lazy default has no such effect.
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -213,10 +211,10 @@ def run_gpu(args):
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     launched = 'RANK' in os.environ            # under torch.distributed.run: always bring RCCL up (also at N=1)
-    if world > 1 or launched:
+    if (world > 1 or launched) and os.environ.get('TFNAS_BENCH_NO_PG', '0') != '1':      # (NO_PG: diagnostics only)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group('nccl', rank=rank, world_size=world)     # (NOT device_id=...: see DESIGN.md 4a, eager RCCL init)
     B = args.batch
     torch.manual_seed(2)
     model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
@@ -262,7 +260,7 @@ def run_gpu(args):
 
     def barrier():
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     barrier()

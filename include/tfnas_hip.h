@@ -307,6 +307,10 @@ typedef struct TfnasPathWs {
  * it against the caller's stream.  One context per concurrently running path. */
 int tfnas_path_create(void **ctx);
 int tfnas_path_destroy(void *ctx);
+/* Use `stream` (owned by the caller, must outlive the context) for the weight-gradient kernels instead of a stream the library
+ * creates.  HIP maps streams onto a few hardware queues in creation order; a caller that has measured which of its streams
+ * really run concurrently (tfnas_amd/streams.py) hands the good ones in here. */
+int tfnas_path_set_side_stream(void *ctx, void *stream);
 
 /* Validate + plan every cell (tfnas_cell_plan), chain the geometry (cell i+1's input extent = cell i's output), lay out
  * the arena.  May be called again on the same context with different candidates / widths (every weight step does). */
@@ -325,11 +329,14 @@ int tfnas_paths_fwd(int npath, void *const *ctx, const float *const *x0, const f
 /* Backward of the same.  dout[p]: gradient of out[p];  dout_lat[p]: device float[nstage] or NULL;
  * produces dx0[p] (if need_dx0), dwmix[p] float[ncell][8] and dcell_lat[p] float[ncell] (soft mode), stage dbetas, and the
  * cells' weight gradients at the g_* pointers of the planned descriptors (need_wgrad cells).
- * On return every path's side stream has been joined to its stream. */
+ * On return every path's side stream has been joined to its stream.
+ * stage_begin / stage_end: walk only the stages [stage_begin, stage_end) (in reverse order; stage_end = -1: to the last one).
+ * A backward may be issued as consecutive segments, last stages first -- (k, -1) then (0, k) -- so that the caller can start
+ * reducing the late stages' weight gradients (89 % of the parameters) across ranks while the early stages are still running. */
 int tfnas_paths_bwd(int npath, void *const *ctx, const float *const *x0, const float *const *wmix,
                     const float *const *cell_lat, float *const *arena, const float *const *dout,
                     const float *const *dout_lat, float *const *dx0, float *const *dwmix, float *const *dcell_lat,
-                    void *const *streams);
+                    void *const *streams, int stage_begin, int stage_end);
 
 /* ---- fused optimizer steps ------------------------------------------------------------------
  * Weight step tail, train_search.py:381-385: clip_grad_norm_(weight_parameters, max_norm) then SGD(momentum, weight decay,

@@ -41,6 +41,7 @@ struct PathCtx {
     uint64_t ring[NRING], dxp;
     TfnasPathWs ws;
     hipStream_t side = nullptr;
+    bool own_side = true;              // false: the caller supplied the side stream (tfnas_path_set_side_stream)
     hipEvent_t fork[TFNAS_MAX_CELLS][3];
     hipEvent_t wdone[TFNAS_MAX_CELLS];
     hipEvent_t join = nullptr, xfork = nullptr;
@@ -235,7 +236,11 @@ extern "C" int tfnas_path_create(void** ctx) {
 // weight-gradient stream on the SAME hardware queue (measured: w-step 21 -> 23.5 ms).
 static int ensure_side(PathCtx* c) {
     if (c->events_ok) return 0;
-    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    if (!c->side) {
+        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        c->own_side = true;
+    }
     for (int i = 0; i < TFNAS_MAX_CELLS && e == hipSuccess; ++i) {
         for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->fork[i][k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wdone[i], hipEventDisableTiming);
@@ -258,9 +263,21 @@ extern "C" int tfnas_path_destroy(void* ctx) {
         }
         (void)hipEventDestroy(c->join);
         (void)hipEventDestroy(c->xfork);
-        (void)hipStreamDestroy(c->side);
+        if (c->own_side) (void)hipStreamDestroy(c->side);
     }
     delete c;
+    return 0;
+}
+
+extern "C" int tfnas_path_set_side_stream(void* ctx, void* stream) {
+    PathCtx* c = static_cast<PathCtx*>(ctx);
+    if (!c || !stream) return TFNAS_ENULL;
+    if (c->side && c->own_side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    c->side = S(stream);
+    c->own_side = false;
     return 0;
 }
 
@@ -407,8 +424,13 @@ int bwd_cell(BwdRun& r, int i) {
 extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* x0, const float* const* wmix,
                                const float* const* cell_lat, float* const* arena, const float* const* dout,
                                const float* const* dout_lat, float* const* dx0, float* const* dwmix,
-                               float* const* dcell_lat, void* const* streams) {
+                               float* const* dcell_lat, void* const* streams, int stage_begin, int stage_end) {
     TRY(check_paths(npath, ctx));
+    {
+        const int ns = static_cast<const PathCtx*>(ctx[0])->pd.nstage;
+        if (stage_end < 0) stage_end = ns;                   // (-1: up to the last stage)
+        if (stage_begin < 0 || stage_begin >= stage_end || stage_end > ns) return TFNAS_ERANGE;
+    }
     if (!x0 || !arena || !dout || !streams) return TFNAS_ENULL;
     BwdRun run[4];
     for (int p = 0; p < npath; ++p) {
@@ -438,9 +460,10 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
     for (int st = 0; st < c0->pd.nstage; ++st) lat_off_end += c0->pd.stage[st].nres;
     int rc = 0;
     int lat_off = lat_off_end;
-    for (int st = c0->pd.nstage - 1; st >= 0 && rc == 0; --st) {
+    for (int st = c0->pd.nstage - 1; st >= stage_begin && rc == 0; --st) {
         const TfnasStage& sg = c0->pd.stage[st];
         lat_off -= sg.nres;
+        if (st >= stage_end) continue;                       // (a later segment of the same backward: already done)
         for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_sink(run[p], st, lat_off);
         for (int j = sg.ncell - 1; j >= 0 && rc == 0; --j)
             for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_cell(run[p], sg.first_cell + j);

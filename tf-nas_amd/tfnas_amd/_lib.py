@@ -79,9 +79,10 @@ _PROTOS = {
     'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
     'tfnas_path_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'tfnas_path_destroy': (C.c_int, [C.c_void_p]),
+    'tfnas_path_set_side_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_path_plan': (C.c_int, [C.c_void_p, C.POINTER(TfnasPathDesc), C.POINTER(TfnasPathWs)]),
     'tfnas_paths_fwd': (C.c_int, [C.c_int] + [_PP] * 8),
-    'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11),
+    'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11 + [C.c_int, C.c_int]),
     'tfnas_pack_ranges': (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
     'tfnas_sgd_clip_step': (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64), C.c_float, C.c_float,

@@ -118,6 +118,9 @@ class PathRunner:
         self.weights = weights                      # WeightArena or None (then need_wgrad paths are refused)
         self._slots = {}
         self._tmpl = {}
+        self.wgrad_streams = {}                     # slot name -> torch stream for that path's weight-gradient kernels
+        self.segment_hook = None                    # callable(cur_stream, side_stream) between the two backward segments
+        self.split_stage = 3                        # stages [3, 6) = stage4..stage6 hold 89 % of the parameters
         self.device = next(model.parameters()).device
         nres = [st.num_res for st in self.stages]
         self.nres_total = sum(nres)
@@ -177,6 +180,10 @@ class PathRunner:
         s = self._slots.get(name)
         if s is None:
             s = self._slots[name] = _Slot(self.lib)
+        ws = self.wgrad_streams.get(name)
+        if ws is not None and getattr(s, 'side', None) is not ws:
+            check(self.lib.tfnas_path_set_side_stream(s.ctx, C.c_void_p(ws.cuda_stream)), 'tfnas_path_set_side_stream')
+            s.side = ws
         return s
 
     def _plan(self, name, idxs, x0h, need_wgrad, need_dx0, need_dbetas):
@@ -266,7 +273,7 @@ class PathRunner:
                 raw_array([None if t is None else t.data_ptr() for t in out_lats]),
                 raw_array([st.cuda_stream for st in streams])), 'tfnas_paths_fwd')
 
-    def _bwd(self, slots, x0s, wmix, clx, douts, dlats, dx0s, dwmix, dclx, streams):
+    def _bwd(self, slots, x0s, wmix, clx, douts, dlats, dx0s, dwmix, dclx, streams, stage_begin=0, stage_end=-1):
         n = len(slots)
 
         def pa(ts):
@@ -275,7 +282,7 @@ class PathRunner:
             check(self.lib.tfnas_paths_bwd(
                 n, raw_array([s.ctx.value for s in slots]), pa(x0s), pa(wmix), pa(clx),
                 raw_array([s.arena.data_ptr() for s in slots]), pa(douts), pa(dlats), pa(dx0s), pa(dwmix), pa(dclx),
-                raw_array([st.cuda_stream for st in streams])), 'tfnas_paths_bwd')
+                raw_array([st.cuda_stream for st in streams]), int(stage_begin), int(stage_end)), 'tfnas_paths_bwd')
 
     def expand_lat(self, CL):
         """[ncell] expected cell latencies -> stage-expanded [sum nres] (differentiable)."""
@@ -378,7 +385,14 @@ class OnePathFn(torch.autograd.Function):
         x0h, = ctx.saved_tensors
         dx0 = torch.empty_like(x0h) if s.pd.need_dx0 else None
         cur = torch.cuda.current_stream(x0h.device)
-        runner._bwd([s], [x0h], [None], [None], [_nhwc(dout)], [None], [dx0], [None], [None], [cur])
+        args = ([s], [x0h], [None], [None], [_nhwc(dout)], [None], [dx0], [None], [None], [cur])
+        hook, k = runner.segment_hook, runner.split_stage
+        if hook is not None and 0 < k < len(runner.stages):
+            runner._bwd(*args, stage_begin=k, stage_end=-1)
+            hook(cur, None)
+            runner._bwd(*args, stage_begin=0, stage_end=k)
+        else:
+            runner._bwd(*args)
         return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None
 
 
@@ -420,8 +434,16 @@ class BiPathFn(torch.autograd.Function):
         dbh.record_stream(side)
         if dxb is not None:
             dxb.record_stream(side)
-        runner._bwd([sa, sb], [x0h, x0h], [None, None], [None, None], [dah, dbh], [None, None], [dxa, dxb],
-                    [None, None], [None, None], [cur, side])
+        args = ([sa, sb], [x0h, x0h], [None, None], [None, None], [dah, dbh], [None, None], [dxa, dxb], [None, None],
+                [None, None], [cur, side])
+        hook, k = runner.segment_hook, runner.split_stage
+        if hook is not None and 0 < k < len(runner.stages):
+            # late stages first; their weight gradients can be reduced across ranks while the early stages still run
+            runner._bwd(*args, stage_begin=k, stage_end=-1)
+            hook(cur, side)
+            runner._bwd(*args, stage_begin=0, stage_end=k)
+        else:
+            runner._bwd(*args)
         cur.wait_stream(side)
         dx = None
         if want_dx:

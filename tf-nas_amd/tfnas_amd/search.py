@@ -57,9 +57,13 @@ class SearchState:
         self._pin = self._pin_ev = None
         self._dp_check = None              # (tensor, expected) of the previous step's sampled-architecture check
         self.arena = self.runner = None
+        self._wgrad_streams = []
         self._op_span = {}
         self._mom_bound = None
         self._msg = self._opt_scratch = self._gnorm = None
+        self._dp = None
+        self._dp_pins, self._dp_seq = None, 0
+        self._comm_stream = None
         self._adam_m = self._adam_v = self._adam_bound = None
         self._adam_t = 0
         self._need_zero_grad = True
@@ -79,6 +83,8 @@ class SearchState:
             self.runner.close()
         self.arena = WeightArena(self.model)
         self.runner = PathRunner(self.model, self.arena, self.storage)
+        if len(self._wgrad_streams) == 2:
+            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1]}
         self._op_params, self._op_span, self._mom_bound = {}, {}, None
         cell_params = set()
         for c in self.model.cells():
@@ -125,42 +131,124 @@ class SearchState:
             sp = self._op_span[key] = self.arena.span(self.op_params(ci, idx))
         return sp
 
-    def fused_weight_step(self, opt_w, idx_lists, grad_clip, group=None):
-        """(all-reduce) + clip_grad_norm_ + SGD over the ranges that received a gradient: the shared parameters (stems, head,
-        classifier) and the sampled candidates -- train_search.py:381-385 in two launches (+ one pack launch and one
-        all-reduce when distributed)."""
-        import ctypes as C
+    def _dp_active(self, group):
         import torch.distributed as dist
-        from . import _lib
-        a = self.arena
-        self._bind_momentum(opt_w)
-        spans = list(self._shared_spans)
-        for idxs in idx_lists:
-            spans.extend(self.op_span(ci, idx) for ci, idx in enumerate(idxs))
-        n = len(spans)
-        off = (C.c_uint64 * n)(*[sp[0] for sp in spans])
-        ln = (C.c_uint64 * n)(*[sp[1] for sp in spans])
-        hp = opt_w.param_groups[0]
-        dev = a.device
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        lib = _lib.lib()
-        g, goff, scale = a.g, None, 1.0
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1 or (world == 1 and dist.is_available() and dist.is_initialized() and FORCE_ALLREDUCE_AT_WORLD_1):
-            global ALLREDUCE_CALLS
-            total = sum(sp[1] for sp in spans)
-            if self._msg is None or self._msg.numel() < total:
-                self._msg = torch.empty(int(total * 1.5), device=dev, dtype=torch.float32)
-            pos, packed = 0, []
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        world = dist.get_world_size(group)
+        return world if (world > 1 or FORCE_ALLREDUCE_AT_WORLD_1) else 0
+
+    def dp_begin(self, idx_lists, group):
+        """Lay out this step's all-reduce message (two regions) and arm the path runner's segment hook: region 1 = head /
+        classifier + the sampled candidates of the late stages (stage4..6: 89 % of the parameters), packed and all-reduced on a
+        communication stream as soon as the first backward segment has been enqueued -- i.e. hidden behind the backward of the
+        early stages; region 2 = stems + early stages, reduced after the backward."""
+        import ctypes as C
+        world = self._dp_active(group)
+        self._dp = None
+        self.runner.segment_hook = None
+        if not world or not OVERLAP_ALLREDUCE:
+            return
+        a, k = self.arena, self.runner.split_stage
+        first_late = sum(st.nblocks for st in self.model.stages()[:k])
+        cells = [(ci, idx) for idxs in idx_lists for ci, idx in enumerate(idxs)]
+        stem_first = self.arena.slot[id(self._shared[0])][0]
+        r1 = [sp for sp in self._shared_spans if sp[0] != stem_first] + [self.op_span(ci, i) for ci, i in cells if ci >= first_late]
+        r2 = [sp for sp in self._shared_spans if sp[0] == stem_first] + [self.op_span(ci, i) for ci, i in cells if ci < first_late]
+        n1, n2 = sum(sp[1] for sp in r1), sum(sp[1] for sp in r2)
+        if self._msg is None or self._msg.numel() < n1 + n2:
+            self._msg = torch.empty(int((n1 + n2) * 1.5), device=a.device, dtype=torch.float32)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=a.device)
+
+        def arrays(spans, base):
+            pos, packed = base, []
             for sp in spans:
                 packed.append(pos)
                 pos += sp[1]
-            goff = (C.c_uint64 * n)(*packed)
-            _lib.check(lib.tfnas_pack_ranges(_lib.ptr(a.g), _lib.ptr(self._msg), n, off, goff, ln, stream), 'tfnas_pack_ranges')
-            self._check_same_architecture(idx_lists, group)
-            dist.all_reduce(self._msg[:total], op=dist.ReduceOp.SUM, group=group)
-            ALLREDUCE_CALLS += 1
-            g, scale = self._msg, 1.0 / world
+            n = len(spans)
+            return ((C.c_uint64 * n)(*[sp[0] for sp in spans]), (C.c_uint64 * n)(*packed), (C.c_uint64 * n)(*[sp[1] for sp in spans]))
+        self._dp = dict(world=world, group=group, r1=r1, r2=r2, n1=n1, n2=n2, a1=arrays(r1, 0), a2=arrays(r2, n1), work=None)
+        self._check_same_architecture(idx_lists, group)
+        self.runner.segment_hook = self._dp_hook
+
+    def _dp_reduce(self, arr, nspans, lo, n, async_op):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        global ALLREDUCE_CALLS
+        a = self.arena
+        stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        _lib.check(_lib.lib().tfnas_pack_ranges(_lib.ptr(a.g), _lib.ptr(self._msg), nspans, arr[0], arr[1], arr[2], stream),
+                   'tfnas_pack_ranges')
+        ALLREDUCE_CALLS += 1
+        return dist.all_reduce(self._msg[lo:lo + n], op=dist.ReduceOp.SUM, group=self._dp['group'], async_op=async_op)
+
+    def _dp_hook(self, cur, side):
+        """Between the two backward segments (path.py): everything region 1 needs has been enqueued on `cur` / `side`."""
+        dp, comm = self._dp, self._comm_stream
+        comm.wait_stream(cur)
+        if side is not None:
+            comm.wait_stream(side)
+        self._msg.record_stream(comm)
+        with torch.cuda.stream(comm):
+            dp['work'] = self._dp_reduce(dp['a1'], len(dp['r1']), 0, dp['n1'], True)
+
+    def fused_weight_step(self, opt_w, idx_lists, grad_clip, group=None):
+        """(all-reduce) + clip_grad_norm_ + SGD over the ranges that received a gradient: the shared parameters (stems, head,
+        classifier) and the sampled candidates -- train_search.py:381-385 in two launches (+ pack launches and all-reduces
+        when distributed, see dp_begin)."""
+        import ctypes as C
+        from . import _lib
+        a = self.arena
+        self._bind_momentum(opt_w)
+        hp = opt_w.param_groups[0]
+        dev = a.device
+        lib = _lib.lib()
+        g, goff, scale = a.g, None, 1.0
+        dp = self._dp
+        self.runner.segment_hook = None
+        world = self._dp_active(group)
+        if dp is not None:
+            cur = torch.cuda.current_stream(dev)
+            if dp['work'] is None:                      # (the backward ran unsegmented: e.g. nothing in the late stages)
+                self._dp_reduce(dp['a1'], len(dp['r1']), 0, dp['n1'], False)
+            self._dp_reduce(dp['a2'], len(dp['r2']), dp['n1'], dp['n2'], False)
+            if dp['work'] is not None:
+                dp['work'].wait()
+                cur.wait_stream(self._comm_stream)
+            spans = dp['r1'] + dp['r2']
+            n = len(spans)
+            off = (C.c_uint64 * n)(*[sp[0] for sp in spans])
+            ln = (C.c_uint64 * n)(*[sp[1] for sp in spans])
+            goff = (C.c_uint64 * n)(*(list(dp['a1'][1]) + list(dp['a2'][1])))
+            g, scale = self._msg, 1.0 / dp['world']
+            self._dp = None
+        else:
+            spans = list(self._shared_spans)
+            for idxs in idx_lists:
+                spans.extend(self.op_span(ci, idx) for ci, idx in enumerate(idxs))
+            n = len(spans)
+            off = (C.c_uint64 * n)(*[sp[0] for sp in spans])
+            ln = (C.c_uint64 * n)(*[sp[1] for sp in spans])
+            if world:                                   # distributed without the two-region overlap: one message after backward
+                global ALLREDUCE_CALLS
+                import torch.distributed as dist
+                total = sum(sp[1] for sp in spans)
+                if self._msg is None or self._msg.numel() < total:
+                    self._msg = torch.empty(int(total * 1.5), device=dev, dtype=torch.float32)
+                pos, packed = 0, []
+                for sp in spans:
+                    packed.append(pos)
+                    pos += sp[1]
+                goff = (C.c_uint64 * n)(*packed)
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(lib.tfnas_pack_ranges(_lib.ptr(a.g), _lib.ptr(self._msg), n, off, goff, ln, stream), 'tfnas_pack_ranges')
+                self._check_same_architecture(idx_lists, group)
+                dist.all_reduce(self._msg[:total], op=dist.ReduceOp.SUM, group=group)
+                ALLREDUCE_CALLS += 1
+                g, scale = self._msg, 1.0 / world
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         nblk = sum((sp[1] + 8191) // 8192 for sp in spans)
         if self._opt_scratch is None or self._opt_scratch.numel() < nblk + 8:
             self._opt_scratch = torch.empty(max(4096, 2 * nblk), device=dev, dtype=torch.float64)
@@ -190,9 +278,16 @@ class SearchState:
             for v in idxs:
                 h = (h * 9 + int(v) + 1) % 16777213
         dev = self.arena.device
-        t = torch.tensor([h, -h], dtype=torch.int32).to(dev, non_blocking=True)
+        # pinned staging both ways: a pageable host->device copy would block the launching thread until the stream has
+        # drained (the previous step), i.e. cost the whole host run-ahead of the step
+        if self._dp_pins is None:
+            self._dp_pins = [(torch.empty(2, dtype=torch.int32, pin_memory=True), torch.empty(2, dtype=torch.int32, pin_memory=True),
+                              torch.empty(2, dtype=torch.int32, device=dev)) for _ in range(6)]
+        src, host, t = self._dp_pins[self._dp_seq % len(self._dp_pins)]
+        self._dp_seq += 1
+        src[0], src[1] = h, -h
+        t.copy_(src, non_blocking=True)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
         host.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
@@ -284,10 +379,24 @@ class SearchState:
                     g.append(p)
 
     def side_stream(self, device):
-        """Second HIP stream for the 'random' path of the w-step (created once per device)."""
+        """Second HIP stream for the 'random' path of the w-step (chosen once per device)."""
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=device)
+            self._pick_streams(device)
         return self._side_stream
+
+    def _pick_streams(self, device):
+        """The three extra streams of a w-step -- path B and the two weight-gradient streams -- are chosen by MEASURED
+        concurrency with the current stream and with each other (streams.py): HIP's stream -> hardware-queue mapping
+        depends on what else the process created (torch's pool, RCCL) and a collision costs 15-40 % of the step."""
+        from .streams import pick_concurrent_streams
+        if PICK_STREAMS and torch.device(device).type == 'cuda':
+            chosen = pick_concurrent_streams(device, 3)
+        else:
+            chosen = [torch.cuda.Stream(device=device)]
+        self._side_stream = chosen[0]
+        self._wgrad_streams = chosen[1:3]
+        if self.runner is not None and len(self._wgrad_streams) == 2:
+            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1]}
 
     # -- host mirror of the log_alphas -------------------------------------------------------------------------
     # The gumbel pass of a w-step needs the sampled candidate indices ON THE HOST (they decide which kernels are
@@ -369,6 +478,10 @@ def _merge_spans(slots, align=64):
 USE_PATHS = os.environ.get('TFNAS_PATHS', '1') != '0'
 # clip + SGD / clip + Adam + projection as fused HIP kernels over the arena ranges (opt_kernels.hip); 0: torch.optim
 FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
+# data parallel: reduce the late stages' gradients while the early stages' backward is still running (SearchState.dp_begin)
+OVERLAP_ALLREDUCE = os.environ.get('TFNAS_OVERLAP_ALLREDUCE', '1') != '0'
+# choose the w-step's side streams by measured concurrency (streams.py); 0: first streams torch / the library hand out
+PICK_STREAMS = os.environ.get('TFNAS_PICK_STREAMS', '1') != '0'
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
@@ -547,6 +660,9 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         model.reset_switches()
     for c, ia in zip(cells, idx_a if idx_b is None else idx_b):
         c.last_idx = ia
+    fused = FUSED_OPT and state._fusable_sgd(opt_w)
+    if fused:
+        state.dp_begin([idx_a] if idx_b is None else [idx_a, idx_b], group)
     if not (FUSED_OPT and state._fusable_sgd(opt_w)) or state._need_zero_grad:
         opt_w.zero_grad()                   # (750 parameters; the fused route never leaves a stale .grad behind)
         state._need_zero_grad = False

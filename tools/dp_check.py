@@ -16,8 +16,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tf-nas_amd'))
-if 'RANK' in os.environ:
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')        # see INTEGRATION.md: 4 compute streams + RCCL's own
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -39,7 +37,7 @@ def main():
     if 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group('nccl', rank=rank, world_size=world)     # (NOT device_id=...: see DESIGN.md 4a, eager RCCL init)
     torch.manual_seed(2)
     model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
     model.set_temperature(5.0)
@@ -64,7 +62,7 @@ def main():
     with open(path, 'w') as f:
         json.dump(out, f)
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

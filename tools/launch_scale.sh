@@ -7,7 +7,6 @@
 set -euo pipefail
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0          # dmabuf IPC (the host driver has no legacy IPC)
-export GPU_MAX_HW_QUEUES=8                   # 4 compute streams + RCCL's
 mkdir -p gpurun_out
 STEPS=${STEPS:-50}; WARMUP=${WARMUP:-10}; PORT=${PORT:-29561}
 if [ "${1:-bench}" = "check" ]; then

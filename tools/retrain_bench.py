@@ -32,7 +32,7 @@ def main():
     if 'RANK' in os.environ:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29571')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group('nccl', rank=rank, world_size=world)     # (NOT device_id=...: see DESIGN.md 4a, eager RCCL init)
     lut = load_lat_lookup('gpu')
     mc = g.initial_mc_num_dddict()
     arch = OrderedDict((st, OrderedDict((b, 1) for b in mc[st])) for st in mc)
@@ -48,13 +48,13 @@ def main():
         me.train_step(model, x, y, crit, opt, 5.0)
     torch.cuda.synchronize()
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         me.train_step(model, x, y, crit, opt, 5.0)
     torch.cuda.synchronize()
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps(dict(metric='derived-network retrain images/sec', value=round(args.batch * world * args.steps / dt, 1),

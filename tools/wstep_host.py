@@ -8,6 +8,13 @@ from tfnas_amd import Network, load_lat_lookup, geometry, search
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device('cuda', 0)
+if os.environ.get('WITH_RCCL') == '1':            # diagnostics: does an initialised process group change the step?
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29581')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, **({'device_id': dev} if os.environ.get('EAGER', '1') == '1' else {}))
+    if os.environ.get('WARM_COLL') == '1':
+        dist.all_reduce(torch.ones(4, device=dev)); torch.cuda.synchronize()
 torch.manual_seed(2)
 model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
 model.set_temperature(5.0)
