@@ -189,3 +189,33 @@ def test_fused_steps_share_state_with_the_torch_optimizers(lut):
     p0 = st._shared[0]
     assert ow.state[p0]['momentum_buffer'].data_ptr() == st.arena.m.data_ptr() + 4 * st.arena.slot[id(p0)][0]
     torch.cuda.synchronize()
+
+
+def test_segmented_backward_and_stream_picker(lut):
+    """tfnas_paths_bwd in two stage segments (what the overlapped all-reduce uses) == one call, bit for bit; the stream picker
+    returns usable streams."""
+    from tfnas_amd import search
+    from tfnas_amd.streams import pick_concurrent_streams
+    ss = pick_concurrent_streams('cuda', 3)
+    assert len(ss) == 3 and len({s.cuda_stream for s in ss}) == 3
+    res = []
+    for hook in (None, lambda cur, side: None):
+        m = _model(lut)
+        st = search.SearchState(m)
+        ow, _ = search.make_optimizers(m)
+        noise = search.NoiseSource(6)
+        gen = torch.Generator(device='cuda').manual_seed(2)
+        x = torch.randn(8, 3, 224, 224, device='cuda', generator=gen)
+        y = torch.randint(0, 100, (8,), device='cuda', generator=gen)
+        orig = st.dp_begin
+
+        def dp_begin(idx_lists, group, _h=hook, _st=st, _o=orig):
+            _o(idx_lists, group)
+            _st.runner.segment_hook = _h                      # force the two-segment route without a process group
+        st.dp_begin = dp_begin
+        for _ in range(2):
+            search.w_step(st, x, y, ow, 5.0, noise.exp('cuda'), noise.rand_pos())
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in m.weight_parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
