@@ -112,3 +112,40 @@ def test_derived_network_train_step_and_eval_match_oracle():
     m2.eval()
     with torch.no_grad():
         assert torch.equal(m2(x.cuda()), em)
+
+
+def test_retrain_schedule_checkpoints_and_resume(tmp_path):
+    """run_retrain (train_eval.py:118-226): config + checkpoints with the reference's keys, resume continues the schedule; the
+    derived network is built from a search checkpoint like `--model_path` does."""
+    import json
+    import os
+    from tfnas_amd import epoch as ep, geometry as g, model_eval as me
+    from tfnas_amd import Network as SearchNetwork
+    from tfnas_amd.latency import load_lat_lookup
+    lut = load_lat_lookup('gpu')
+    masks = g.make_mc_mask_dddict()
+    torch.manual_seed(0)
+    sn = SearchNetwork(10, g.get_mc_num_dddict(masks, is_max=True), lut)
+    with torch.no_grad():
+        for p in sn.arch_parameters():
+            p.add_(torch.randn(p.shape))
+    ck = ep.save_search_checkpoint(str(tmp_path), 7, {'module.' + k: v for k, v in sn.state_dict().items()}, masks)
+    model = me.build_derived_network(10, model_path=ck, dropout_rate=0.1, drop_connect_rate=0.1)
+    gen = torch.Generator().manual_seed(1)
+
+    def queue(n):
+        return lambda e: [(torch.randn(8, 3, 64, 64, generator=gen), torch.randint(0, 10, (8,), generator=gen)) for _ in range(n)]
+    h = me.run_retrain(str(tmp_path / 'rt'), model, queue(3), queue(2), epochs=3, lr=0.1, log=lambda s: None)
+    assert [r['epoch'] for r in h] == [0, 1, 2] and h[0]['lr'] > h[1]['lr'] > h[2]['lr'] > 0
+    cp = torch.load(tmp_path / 'rt' / 'checkpoint.pth.tar', weights_only=False)
+    assert set(cp) == {'epoch', 'state_dict', 'best_acc_top1', 'best_acc_top5', 'optimizer'} and cp['epoch'] == 3
+    assert all(k.startswith('module.') for k in cp['state_dict'])
+    cfg = json.load(open(tmp_path / 'rt' / 'model.config'))
+    assert cfg == model.config
+    assert os.path.exists(tmp_path / 'rt' / 'model_best.pth.tar') or cp['best_acc_top1'] == 0.0
+    m2 = me.build_derived_network(10, config_path=str(tmp_path / 'rt' / 'model.config'), dropout_rate=0.1, drop_connect_rate=0.1)
+    h2 = me.run_retrain(str(tmp_path / 'rt2'), m2, queue(2), queue(1), epochs=4, lr=0.1,
+                        snapshot=str(tmp_path / 'rt' / 'checkpoint.pth.tar'), log=lambda s: None)
+    assert [r['epoch'] for r in h2] == [3]
+    for v in m2.state_dict().values():
+        assert torch.isfinite(v.float()).all()

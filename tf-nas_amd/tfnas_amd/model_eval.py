@@ -229,3 +229,75 @@ def validate(model, val_queue, criterion=None):
         top1.update(vals[1], n)
         top5.update(vals[2], n)
     return top1.avg, top5.avg, objs.avg
+
+
+def build_derived_network(num_classes, model_path=None, config_path=None, dropout_rate=0.2, drop_connect_rate=0.2):
+    """train_eval.py:102-115: the derived network from a search checkpoint (``--model_path``: parse the architecture, widths
+    from its masks) or from an exported ``model.config`` (``--config_path``)."""
+    import json
+    import os
+    if model_path and os.path.isfile(model_path):
+        from .epoch import get_op_and_depth_weights, parse_architecture
+        ck = torch.load(model_path, map_location='cpu', weights_only=False)
+        parsed = parse_architecture(*get_op_and_depth_weights(ck['state_dict']))
+        return Network(num_classes, parsed, geometry.get_mc_num_dddict(ck['mc_mask_dddict']), None, dropout_rate,
+                       drop_connect_rate)
+    if config_path and os.path.isfile(config_path):
+        return NetworkCfg(num_classes, json.load(open(config_path)), None, dropout_rate, drop_connect_rate)
+    raise ValueError('invalid model_path and config_path')
+
+
+def run_retrain(save_dir, model, make_train_queue, make_val_queue, *, epochs=250, lr=0.2, momentum=0.9, weight_decay=4e-5,
+                label_smooth=0.1, grad_clip=5.0, batch_size=256, snapshot=None, device='cuda', group=None, log=print):
+    """The retrain schedule of train_eval.py:118-226: SGD + cosine learning rate (5 warm-up epochs of linearly increasing rate
+    when batch_size > 256), label-smoothed training loss, plain cross-entropy validation every epoch, ``checkpoint.pth.tar`` /
+    ``model_best.pth.tar`` with the reference's keys ('epoch', 'state_dict' with DataParallel's ``module.`` prefix,
+    'best_acc_top1', 'best_acc_top5', 'optimizer'), resume from ``snapshot``, ``model.config`` written next to them."""
+    import json
+    import math
+    import os
+    import shutil
+    from .search import AverageMeter, accuracy
+    os.makedirs(save_dir, exist_ok=True)
+    dev = torch.device(device)
+    model = model.to(dev)
+    num_classes = model.classifier.out_features
+    with open(os.path.join(save_dir, 'model.config'), 'w') as f:
+        json.dump(model.config, f, indent=4)
+    crit_smooth = CrossEntropyLabelSmooth(num_classes, label_smooth)
+    opt = torch.optim.SGD(model.parameters(), lr, momentum=momentum, weight_decay=weight_decay)
+    best1 = best5 = 0.0
+    start = 0
+    if snapshot:
+        ck = torch.load(snapshot, map_location=dev, weights_only=False)
+        start, best1, best5 = ck['epoch'], ck['best_acc_top1'], ck['best_acc_top5']
+        model.load_state_dict({k[len('module.'):] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()})
+        opt.load_state_dict(ck['optimizer'])
+    history = []
+    for epoch in range(start, epochs):
+        cur = 0.5 * lr * (1.0 + math.cos(math.pi * epoch / float(epochs)))          # CosineAnnealingLR(T_max=epochs).get_lr()
+        warm = epoch < 5 and batch_size > 256
+        for g in opt.param_groups:
+            g['lr'] = cur * (epoch + 1) / 5.0 if warm else cur
+        objs, top1 = AverageMeter(), AverageMeter()
+        for x, y in make_train_queue(epoch):
+            x, y = x.to(dev, non_blocking=True), y.to(dev, non_blocking=True)
+            loss, logits = train_step(model, x, y, crit_smooth, opt, grad_clip, group)
+            p1, = accuracy(logits, y, topk=(1,))
+            vals = torch.stack([loss.float(), p1]).tolist()
+            objs.update(vals[0], x.size(0))
+            top1.update(vals[1], x.size(0))
+        v1, v5, vobj = validate(model, make_val_queue(epoch))
+        is_best = v1 > best1
+        if is_best:
+            best1, best5 = v1, v5
+        state = {'epoch': epoch + 1, 'state_dict': {'module.' + k: v for k, v in model.state_dict().items()},
+                 'best_acc_top1': best1, 'best_acc_top5': best5, 'optimizer': opt.state_dict()}
+        path = os.path.join(save_dir, 'checkpoint.pth.tar')
+        torch.save(state, path)
+        if is_best:
+            shutil.copyfile(path, os.path.join(save_dir, 'model_best.pth.tar'))
+        history.append(dict(epoch=epoch, lr=opt.param_groups[0]['lr'], train_acc=top1.avg, train_obj=objs.avg, val_top1=v1,
+                            val_top5=v5, val_obj=vobj))
+        log('Epoch %d lr %e train_acc %f val_top1 %f val_top5 %f' % (epoch, opt.param_groups[0]['lr'], top1.avg, v1, v5))
+    return history
