@@ -6,6 +6,11 @@ NO fallback: if the library is missing or an entry point returns non-zero, a Run
 import ctypes as C
 import os
 
+# torch FIRST: the PyTorch-ROCm wheel bundles its own libamdhip64.so.  If libtfnas_hip.so were loaded before torch, the dynamic
+# loader would bind it to the system ROCm's HIP runtime instead, the process would hold two HIP runtimes, and every launch on a
+# torch-allocated pointer would fail with hipErrorNoDevice (100) -- seen when build() and smoke() ran in one process.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtfnas_hip.so')
 LIB_PATH_BF16 = os.path.join(_HERE, 'libtfnas_hip_bf16.so')     # same sources + the bf16-storage mode (csrc/Makefile)
