@@ -149,11 +149,23 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad, kink_tau=None):
         res['dwmix'] = err(w_m.grad, w_o.grad)
     if need_wgrad:
         k = 0
-        for i in idxs:
+        for gi, i in enumerate(idxs):
             names = ['expand', 'dw', 'proj'] + (['se_rw', 'se_rb', 'se_ew', 'se_eb'] if o.m_ops[i].se_channels else [])
             op = o.m_ops[i].params()
+            # A weight gradient sums over every pixel, the kinked ones included: an element that takes the other side of
+            # relu'(0) moves an entry of dW_expand / dW_dw by up to |its gradient| x |the other operand|.  Allow exactly
+            # that much (count of kinked elements of this candidate x max|dEh| x max(|x|, |Eh|)); 0 without kinks.
+            allow = 0.0
+            if use_kink:
+                det = details[gi]
+                nk = float(relu_kink_masks(det, o.m_ops[i].kernel_size, o.m_ops[i].stride, kink_tau).sum())
+                allow = nk * float(det['Eh'].grad.abs().max()) * max(float(x.abs().max()), float(det['Eh'].abs().max()))
+                res['g%d.kink_allow' % i] = (0.0, allow)
             for nme in names:
-                res['g%d.grad_%s' % (i, nme)] = err(params[k].grad, op[nme].grad)
+                e_abs, e_ref = err(params[k].grad, op[nme].grad)
+                if nme in ('expand', 'dw'):
+                    e_abs = max(0.0, e_abs - allow)
+                res['g%d.grad_%s' % (i, nme)] = (e_abs, e_ref)
                 k += 1
     for p in params:
         p.grad = None

@@ -40,10 +40,16 @@ def _inputs(cfg):
     return o, m, x, r, e
 
 
+# ReLU cells: elements downstream of a pre-activation within KINK_TAU of 0 in the oracle are compared for boundedness only
+# (tests/_hipcheck.py::relu_kink_masks): which side of relu'(0) such an element takes depends on the summation order of the
+# expand GEMM (real_s1b2_56 has 5.4 M pre-activations; one flipped when the K order inside a chunk changed)
+KINK_TAU = 4e-6
+
+
 @pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_soft_mode_all_stages(cfg):
     o, m, x, r, e = _inputs(cfg)
-    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=False)
+    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=KINK_TAU)
     assert not hc.worst(res), hc.worst(res)
 
 
@@ -51,7 +57,7 @@ def test_soft_mode_all_stages(cfg):
 @pytest.mark.parametrize('idx', [0, 3, 5, 6])
 def test_sampled_mode_with_weight_grads(cfg, idx):
     o, m, x, r, e = _inputs(cfg)
-    res = hc.compare_cell(o, m, x, r, e, [idx], need_wgrad=True)
+    res = hc.compare_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=KINK_TAU)
     assert not hc.worst(res), hc.worst(res)
 
 

@@ -38,51 +38,68 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[2][NT]) {
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
 }
 
-template <int NT, bool AK, bool BKC, class FA, class FB>
-__device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4 (&acc)[2][NT], float* lds) {
+struct XfId {   // transform of a one-piece loader: the value is already final
+    __device__ __forceinline__ f32x4 operator()(f32x4 v, int, int, int) const { return v; }
+};
+
+// Two-phase operand loaders.  `la(c, i0, i1)` / `lb(c, i0, i1)` only ISSUE the global loads of K-chunk c and return the raw
+// registers (any struct); `xa(raw, c, i0, i1)` / `xb(...)` turn them into the f32x4 that goes to LDS (normalise, activate,
+// mask rows / columns outside the problem).  The split matters: the loads of chunk c+1 are issued before the MFMAs of chunk
+// c and must not be waited for until after them.  With a one-piece loader whose element-wise math sits in the same
+// conditional region as its load, the compiler put `s_waitcnt vmcnt(0)` straight after every load -- 2 to 5 serialized DRAM
+// round trips per K-chunk in front of the MFMAs (ISA of round 1/2's k_project_* / k_expand_dgrad / k_*_wgrad).  Loaders
+// therefore load unconditionally from clamped addresses and mask in the transform.
+template <int NT, bool AK, bool BKC, class LA, class XA, class LB, class XB>
+__device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, int nchunks, f32x4 (&acc)[2][NT],
+                                               float* lds) {
     using T = GT<NT>;
+    using RA = decltype(la(0, 0, 0));
+    using RB = decltype(lb(0, 0, 0));
     const int tid = threadIdx.x, lane = tid & 63, wrow = (tid >> 6) * 32;
     const int lr = lane & 15, lk = lane >> 4;
-    f32x4 ra[2], rb[T::B_ITERS];
+    RA ra[2];
+    RB rb[T::B_ITERS];
 
+#define TFNAS_A_IDX(i) const int idx = tid + 256 * (i), a0_ = AK ? (idx >> 2) : (idx >> 5), a1_ = AK ? (idx & 3) * 4 : (idx & 31) * 4
+#define TFNAS_B_IDX(i)                                                      \
+    const int idx = tid + 256 * (i), b0_ = BKC ? (idx >> 2) : idx / (T::BN / 4), \
+              b1_ = BKC ? (idx & 3) * 4 : (idx % (T::BN / 4)) * 4
 #define TFNAS_GLOAD(c)                                                                      \
     {                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
-            const int idx = tid + 256 * i;                                                  \
-            ra[i] = AK ? fa((c), idx >> 2, (idx & 3) * 4) : fa((c), idx >> 5, (idx & 31) * 4); \
+            TFNAS_A_IDX(i);                                                                 \
+            ra[i] = la((c), a0_, a1_);                                                      \
         }                                                                                   \
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
-            const int idx = tid + 256 * i;                                                  \
-            if (idx < T::B_ITEMS)                                                           \
-                rb[i] = BKC ? fb((c), idx >> 2, (idx & 3) * 4)                              \
-                            : fb((c), idx / (T::BN / 4), (idx % (T::BN / 4)) * 4);          \
+            TFNAS_B_IDX(i);                                                                 \
+            if (idx < T::B_ITEMS) rb[i] = lb((c), b0_, b1_);                                \
         }                                                                                   \
     }
-#define TFNAS_SSTORE(As, Bs)                                                                \
+#define TFNAS_SSTORE(c, As, Bs)                                                             \
     {                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
-            const int idx = tid + 256 * i;                                                  \
+            TFNAS_A_IDX(i);                                                                 \
+            const f32x4 v = xa(ra[i], (c), a0_, a1_);                                       \
             if (AK) {                                                                       \
-                const int row = idx >> 2, kl = (idx & 3) * 4;                               \
-                (As)[(kl + 0) * T::LDA + row] = ra[i].x;                                    \
-                (As)[(kl + 1) * T::LDA + row] = ra[i].y;                                    \
-                (As)[(kl + 2) * T::LDA + row] = ra[i].z;                                    \
-                (As)[(kl + 3) * T::LDA + row] = ra[i].w;                                    \
+                (As)[(a1_ + 0) * T::LDA + a0_] = v.x;                                       \
+                (As)[(a1_ + 1) * T::LDA + a0_] = v.y;                                       \
+                (As)[(a1_ + 2) * T::LDA + a0_] = v.z;                                       \
+                (As)[(a1_ + 3) * T::LDA + a0_] = v.w;                                       \
             } else {                                                                        \
-                st4(&(As)[(idx >> 5) * T::LDA + (idx & 31) * 4], ra[i]);                    \
+                st4(&(As)[a0_ * T::LDA + a1_], v);                                          \
             }                                                                               \
         }                                                                                   \
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
-            const int idx = tid + 256 * i;                                                  \
+            TFNAS_B_IDX(i);                                                                 \
             if (idx < T::B_ITEMS) {                                                         \
+                const f32x4 v = xb(rb[i], (c), b0_, b1_);                                   \
                 if (BKC) {                                                                  \
-                    const int n = idx >> 2, kl = (idx & 3) * 4;                             \
-                    (Bs)[(kl + 0) * T::LDB + n] = rb[i].x;                                  \
-                    (Bs)[(kl + 1) * T::LDB + n] = rb[i].y;                                  \
-                    (Bs)[(kl + 2) * T::LDB + n] = rb[i].z;                                  \
-                    (Bs)[(kl + 3) * T::LDB + n] = rb[i].w;                                  \
+                    (Bs)[(b1_ + 0) * T::LDB + b0_] = v.x;                                   \
+                    (Bs)[(b1_ + 1) * T::LDB + b0_] = v.y;                                   \
+                    (Bs)[(b1_ + 2) * T::LDB + b0_] = v.z;                                   \
+                    (Bs)[(b1_ + 3) * T::LDB + b0_] = v.w;                                   \
                 } else {                                                                    \
-                    st4(&(Bs)[(idx / (T::BN / 4)) * T::LDB + (idx % (T::BN / 4)) * 4], rb[i]); \
+                    st4(&(Bs)[b0_ * T::LDB + b1_], v);                                      \
                 }                                                                           \
             }                                                                               \
         }                                                                                   \
@@ -95,7 +112,7 @@ __device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4
 
     if (nchunks > 0) {
         TFNAS_GLOAD(0);
-        TFNAS_SSTORE(As0, Bs0);
+        TFNAS_SSTORE(0, As0, Bs0);
     }
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
@@ -116,12 +133,160 @@ __device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4
             }
         }
         if (more) {
-            if (c & 1) { TFNAS_SSTORE(As0, Bs0); } else { TFNAS_SSTORE(As1, Bs1); }
+            if (c & 1) { TFNAS_SSTORE(c + 1, As0, Bs0); } else { TFNAS_SSTORE(c + 1, As1, Bs1); }
         }
         __syncthreads();
     }
 #undef TFNAS_GLOAD
 #undef TFNAS_SSTORE
+#undef TFNAS_A_IDX
+#undef TFNAS_B_IDX
+}
+
+// A-direct variant for K-contiguous A operands (AK).  In the LDS-staged loop each wave only ever reads back its OWN 32 rows
+// of the A tile, and the float4 a thread loads for the staging store (4 consecutive k of one row) already sits in a lane
+// that an MFMA can take it from: lane (lr, lk) asks for A(row = wrow + 16 i + lr, k = 4 lk .. 4 lk + 3) and MFMA step j consumes
+// component j, i.e. K slot lk of step j carries k = 4 lk + j.  A sum over k does not care about the order, so the B tile is
+// stored with its rows permuted the same way (k -> row (k & 3) * 4 + (k >> 2)) and read exactly as before.  That removes
+// the transposing scalar LDS stores of A (the bank-conflicted part of the staging), its fragment reads and half of the LDS
+// footprint; global access pattern (64-byte row pieces) and accumulator layout are unchanged.
+template <int NT, bool BKC, bool PF2, class LA, class XA, class LB, class XB>
+__device__ __forceinline__ void gemm_mainloop_adirect(LA& la, XA& xa, LB& lb, XB& xb, int nchunks, f32x4 (&acc)[2][NT],
+                                                      float* lds) {
+    using T = GT<NT>;
+    using RA = decltype(la(0, 0, 0));
+    using RB = decltype(lb(0, 0, 0));
+    const int tid = threadIdx.x, lane = tid & 63, wrow = (tid >> 6) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    RA ra[2];
+    RB rb[T::B_ITERS];
+    f32x4 cur[2];
+
+#define TFNAS_B_IDX(i)                                                      \
+    const int idx = tid + 256 * (i), b0_ = BKC ? (idx >> 2) : idx / (T::BN / 4), \
+              b1_ = BKC ? (idx & 3) * 4 : (idx % (T::BN / 4)) * 4
+#define TFNAS_GLOAD(c)                                                                      \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra[i] = la((c), wrow + 16 * i + lr, 4 * lk); \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            TFNAS_B_IDX(i);                                                                 \
+            if (idx < T::B_ITEMS) rb[i] = lb((c), b0_, b1_);                                \
+        }                                                                                   \
+    }
+#define TFNAS_SSTORE(c, Bs)                                                                 \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) cur[i] = xa(ra[i], (c), wrow + 16 * i + lr, 4 * lk); \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            TFNAS_B_IDX(i);                                                                 \
+            if (idx < T::B_ITEMS) {                                                         \
+                const f32x4 v = xb(rb[i], (c), b0_, b1_);                                   \
+                if (BKC) {   /* k = b1_ + t  ->  row 4 t + b1_ / 4 */                       \
+                    const int r0_ = b1_ >> 2;                                               \
+                    (Bs)[(r0_ + 0) * T::LDB + b0_] = v.x;                                   \
+                    (Bs)[(r0_ + 4) * T::LDB + b0_] = v.y;                                   \
+                    (Bs)[(r0_ + 8) * T::LDB + b0_] = v.z;                                   \
+                    (Bs)[(r0_ + 12) * T::LDB + b0_] = v.w;                                  \
+                } else {                                                                    \
+                    st4(&(Bs)[((b0_ & 3) * 4 + (b0_ >> 2)) * T::LDB + b1_], v);             \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+    }
+
+    float* Bs0 = lds;
+    float* Bs1 = lds + T::B_FLOATS;
+#define TFNAS_MFMAS(Bs)                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                      \
+        const int k = ks * 4 + lk;                                                          \
+        const float a0 = cur[0][ks], a1 = cur[1][ks];                                       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                    \
+            const float b = (Bs)[k * T::LDB + 16 * j + lr];                                 \
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);    \
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);    \
+        }                                                                                   \
+    }
+    if (PF2) {
+        // prefetch distance 2: the loads of chunk c+2 are issued before the MFMAs of chunk c and consumed after the MFMAs
+        // of chunk c+1 -- one chunk of MFMAs (0.2-0.75 us per wave) is shorter than a loaded-HBM round trip (1-2 us), and
+        // the 2-3.5 resident waves per SIMD these launches reach do not cover the difference.  Two raw register sets,
+        // alternating statically (loop unrolled by two).
+        RA ra2[2];
+        RB rb2[T::B_ITERS];
+#define TFNAS_GLOAD2(c)                                                                     \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra2[i] = la((c), wrow + 16 * i + lr, 4 * lk); \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            TFNAS_B_IDX(i);                                                                 \
+            if (idx < T::B_ITEMS) rb2[i] = lb((c), b0_, b1_);                               \
+        }                                                                                   \
+    }
+#define TFNAS_SSTORE2(c, Bs)                                                                \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) cur[i] = xa(ra2[i], (c), wrow + 16 * i + lr, 4 * lk); \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
+            TFNAS_B_IDX(i);                                                                 \
+            if (idx < T::B_ITEMS) {                                                         \
+                const f32x4 v = xb(rb2[i], (c), b0_, b1_);                                  \
+                if (BKC) {                                                                  \
+                    const int r0_ = b1_ >> 2;                                               \
+                    (Bs)[(r0_ + 0) * T::LDB + b0_] = v.x;                                   \
+                    (Bs)[(r0_ + 4) * T::LDB + b0_] = v.y;                                   \
+                    (Bs)[(r0_ + 8) * T::LDB + b0_] = v.z;                                   \
+                    (Bs)[(r0_ + 12) * T::LDB + b0_] = v.w;                                  \
+                } else {                                                                    \
+                    st4(&(Bs)[((b0_ & 3) * 4 + (b0_ >> 2)) * T::LDB + b1_], v);             \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+    }
+        if (nchunks > 0) {
+            TFNAS_GLOAD(0);
+            TFNAS_SSTORE(0, Bs0);
+        }
+        if (nchunks > 1) TFNAS_GLOAD2(1);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 2 < nchunks) TFNAS_GLOAD(c + 2);
+            TFNAS_MFMAS(Bs0);
+            if (c + 1 < nchunks) TFNAS_SSTORE2(c + 1, Bs1);
+            __syncthreads();
+            if (c + 1 >= nchunks) break;
+            if (c + 3 < nchunks) TFNAS_GLOAD2(c + 3);
+            TFNAS_MFMAS(Bs1);
+            if (c + 2 < nchunks) TFNAS_SSTORE(c + 2, Bs0);
+            __syncthreads();
+        }
+#undef TFNAS_GLOAD2
+#undef TFNAS_SSTORE2
+    } else {
+        if (nchunks > 0) {
+            TFNAS_GLOAD(0);
+            TFNAS_SSTORE(0, Bs0);
+        }
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const float* Bs = (c & 1) ? Bs1 : Bs0;
+            const bool more = (c + 1 < nchunks);
+            if (more) TFNAS_GLOAD(c + 1);
+            TFNAS_MFMAS(Bs);
+            if (more) {
+                if (c & 1) { TFNAS_SSTORE(c + 1, Bs0); } else { TFNAS_SSTORE(c + 1, Bs1); }
+            }
+            __syncthreads();
+        }
+    }
+#undef TFNAS_MFMAS
+#undef TFNAS_GLOAD
+#undef TFNAS_SSTORE
+#undef TFNAS_B_IDX
+}
+
+// One-piece loaders (the value is ready when the functor returns): for operands whose loads the compiler already keeps in
+// flight across the MFMAs (plain unconditional loads, small weight tiles).
+template <int NT, bool AK, bool BKC, class FA, class FB>
+__device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4 (&acc)[2][NT], float* lds) {
+    XfId id;
+    gemm_mainloop2<NT, AK, BKC>(fa, id, fb, id, nchunks, acc, lds);
 }
 
 // Per-column sums of the accumulator tile (rows outside the problem contribute exact zeros because the

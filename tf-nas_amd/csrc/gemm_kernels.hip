@@ -28,11 +28,50 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
     return v;
 }
 
+// main loop of the GEMMs whose A operand is K-contiguous: A straight into the MFMA lanes (build with -DTFNAS_A_STAGED for the
+// LDS-staged loop of rounds 1-2, A/B measurements)
+#ifdef TFNAS_A_STAGED
+#define GEMM_AK(NT, BKC, la, xa, lb, xb, n, acc, lds) gemm_mainloop2<NT, true, BKC>(la, xa, lb, xb, n, acc, lds)
+#else
+#ifndef TFNAS_PF2
+#define TFNAS_PF2 false
+#endif
+// resident workgroups per CU the row-tiled GEMM kernels are compiled for (register cap 512 / n per lane): 5-/7-tile and
+// narrower variants
+#ifndef TFNAS_LB_BIG
+#define TFNAS_LB_BIG 3
+#endif
+#ifndef TFNAS_LB_SMALL
+#define TFNAS_LB_SMALL 4
+#endif
+#define GEMM_AK(NT, BKC, la, xa, lb, xb, n, acc, lds) gemm_mainloop_adirect<NT, BKC, TFNAS_PF2>(la, xa, lb, xb, n, acc, lds)
+#endif
+
+// -DTFNAS_WG_TIMING (tools/wg_timeline.py): per-workgroup wall-clock stamps (100 MHz s_memrealtime) of the weight-gradient
+// GEMMs: [wg][0..3] = start, after prologue, after K loop, end
+#ifdef TFNAS_WG_TIMING
+__device__ unsigned long long g_wgt[4 * 16384];
+#define WGT(slot)                                                                                                      \
+    if (threadIdx.x == 0) {                                                                                            \
+        const unsigned f_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                            \
+        if (f_ < 16384) g_wgt[4 * f_ + (slot)] = wall_clock64();                                                       \
+    }
+extern "C" int tfnas_dbg_wg_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define WGT(slot)
+#endif
+
+// raw registers of the two-phase loaders (gemm_core.h): what the load phase leaves for the transform phase
+struct Raw2 { f32x4 a, b; };             // two stream pieces (D | gate,  dOut | Pr,  dEh | E)
+struct RawWS { f32x4 w; float s; };      // a weight quad and its row scale
+
 // ============================================================================ expand forward
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT, bool STEM>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
                                                     float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
@@ -66,7 +105,8 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_fwd(TfnasCellDe
             const int col = n0 + n, k = c * 16 + kl;
             return (col < mc) ? ld4_guard(w + (size_t)col * ic, k, ic, !STEM) : zero4();
         };
-        gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
+        XfId id;
+        GEMM_AK(NT, true, fa, id, fb, id, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < P && n0 + lc < mcp) stS4_nt(E, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -82,7 +122,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_fwd(TfnasCellDe
 // (launch bounds: the 7-tile variant otherwise takes 149 VGPRs + 56 AGPRs = 2 waves/SIMD, measured 1.5 resident; capping
 //  it at 168 registers buys the third wave: -17 % on the 112-channel cells)
 template <int NT, int ACT>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
+__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
                                                      float* __restrict__ part, int nsplit, float* __restrict__ prp) {
@@ -90,9 +130,20 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellD
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // nsplit > 1 (under-filled launches: few row tiles, long K): K-split ks of group g adds chunks [cb, ce); split 0
     // writes Pr, split z > 0 its partial tile to prp[z-1]; k_pr_reduce sums them and takes the BN3 statistics
-    const int g = blockIdx.z / nsplit, ks = blockIdx.z - g * nsplit;
+    // blockIdx.z -> group in order of DEcreasing K (= mid width): a workgroup's run time is proportional to its group's K
+    // and the launch is 1-2 rounds of resident workgroups, so the long ones must not be the last to start (with the
+    // natural order the 7x7 cells dispatched the widest group last: 1.5 instead of 1.0 long-workgroup times)
+    const int zr = blockIdx.z / nsplit, ks = blockIdx.z - zr * nsplit;
+    int g = 0;
+    for (int c = 0; c < d.G; ++c) {
+        int rank = 0;
+        for (int o = 0; o < d.G; ++o) rank += (d.g[o].mcp > d.g[c].mcp) || (d.g[o].mcp == d.g[c].mcp && o < c);
+        if (rank == zr) g = c;
+    }
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0, w_al = (mc & 3) == 0;
+    const float* gbase = has_se ? gate : D;        // the gate load is unconditional (see gemm_core.h: no branches
+    const size_t se01 = has_se ? 1 : 0;            // around the loads of the prefetch phase)
     const float* __restrict__ w = d.g[g].w_proj;
     const int n0 = blockIdx.y * T::BN;
     const int HW = d.Ho * d.Wo, Po = d.N * HW, oc = d.oc, M = d.M;
@@ -114,23 +165,31 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_fwd(TfnasCellD
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
+        auto la = [&](int c, int row, int kl) -> Raw2 {
+            const int p = min(rt * 128 + row, Po - 1), k = min((cb + c) * 16 + kl, mcp - 4);
+            Raw2 r;
+            r.a = ldS4_raw(D, (size_t)p * M + off + k, d.stor);
+            r.b = ld4(gbase + ((size_t)(p / HW) * M + off + k) * se01);     // no SE: one fixed (ignored) quad
+            return r;
+        };
+        auto xa = [&](Raw2 r, int c, int row, int kl) -> f32x4 {
             const int p = rt * 128 + row, k = (cb + c) * 16 + kl;
             if (p >= Po || k >= mcp) return zero4();
-            f32x4 v = ldS4(D, (size_t)p * M + off + k, d.stor);
+            f32x4 v = ldS4_fin(r.a, d.stor);
             const float2 c0 = cst[k], c1 = cst[k + 1], c2 = cst[k + 2], c3 = cst[k + 3];
             v.x = act_f<ACT>((v.x - c0.x) * c0.y);
             v.y = act_f<ACT>((v.y - c1.x) * c1.y);
             v.z = act_f<ACT>((v.z - c2.x) * c2.y);
             v.w = act_f<ACT>((v.w - c3.x) * c3.y);
-            if (has_se) v *= ld4(gate + (size_t)(p / HW) * M + off + k);
+            if (has_se) v *= r.b;
             return v;
         };
         auto fb = [&](int c, int n, int kl) -> f32x4 {
             const int o = n0 + n, k = (cb + c) * 16 + kl;
             return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, w_al) : zero4();
         };
-        gemm_mainloop<NT, true, true>(fa, fb, nchunks, acc, lds);
+        XfId id;
+        GEMM_AK(NT, true, la, xa, fb, id, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < oc) st4(dst + ((size_t)g * Po + p) * oc + n0 + lc, v);
@@ -219,7 +278,7 @@ __device__ __forceinline__ f32x4 bn3_dp(const Bn3Tab& t, int o, f32x4 dout, f32x
 // ============================================================================ project dgrad
 // dZ[p][off_g + c] = sum_o dP_g[p][o] * w_proj_g[o][c]
 template <int NT>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
                                                        const double* __restrict__ red3,
@@ -248,16 +307,24 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_project_dgrad(TfnasCel
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
+        auto la = [&](int c, int row, int kl) -> Raw2 {
+            const int p = min(rt * 128 + row, Po - 1), o = min(c * 16 + kl, oc - 4);
+            Raw2 r;
+            r.a = ld4(dout + (size_t)p * oc + o);
+            r.b = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+            return r;
+        };
+        auto xa = [&](Raw2 r, int c, int row, int kl) -> f32x4 {
             const int p = rt * 128 + row, o = c * 16 + kl;
             if (p >= Po || o >= oc) return zero4();
-            return bn3_dp(tab, o, ld4(dout + (size_t)p * oc + o), ld4(Pr + ((size_t)g * Po + p) * oc + o));
+            return bn3_dp(tab, o, r.a, r.b);
         };
         auto fb = [&](int c, int kl, int n) -> f32x4 {
             const int o = c * 16 + kl;
             return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, w_al) : zero4();
         };
-        gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
+        XfId id;
+        GEMM_AK(NT, false, la, xa, fb, id, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -279,9 +346,12 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
                                                        int ntiles_o, float* __restrict__ part, size_t out_size) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    WGT(0)
     const int g = blockIdx.z / ntiles_o, n0 = (blockIdx.z % ntiles_o) * T::BN;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0;
+    const float* gbase = has_se ? gate : D;
+    const size_t se01 = has_se ? 1 : 0;
     size_t poff = 0;
     for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * d.oc;
     float* __restrict__ gw = part + (size_t)blockIdx.x * out_size + poff;
@@ -305,21 +375,37 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
 
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
-    auto fa = [&](int c, int kl, int m) -> f32x4 {
+    auto la = [&](int c, int kl, int m) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1), ch = min(m0 + m, mcp - 4);
+        Raw2 r;
+        r.a = ldS4_raw(D, (size_t)p * M + off + ch, d.stor);
+        r.b = ld4(gbase + ((size_t)(p / HW) * M + off + ch) * se01);        // no SE: one fixed (ignored) quad
+        return r;
+    };
+    auto xa = [&](Raw2 r, int c, int kl, int m) -> f32x4 {
         const int p = r0 + c * 16 + kl, ch = m0 + m;
         if (p >= r1 || ch >= mcp) return zero4();
-        f32x4 v = ldS4(D, (size_t)p * M + off + ch, d.stor);
+        f32x4 v = ldS4_fin(r.a, d.stor);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
-        if (has_se) v *= ld4(gate + (size_t)(p / HW) * M + off + ch);
+        if (has_se) v *= r.b;
         return v;
     };
-    auto fb = [&](int c, int kl, int n) -> f32x4 {
+    auto lb = [&](int c, int kl, int n) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1), o = min(n0 + n, oc - 4);
+        Raw2 r;
+        r.a = ld4(dout + (size_t)p * oc + o);
+        r.b = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+        return r;
+    };
+    auto xb = [&](Raw2 r, int c, int kl, int n) -> f32x4 {
         const int p = r0 + c * 16 + kl, o = n0 + n;
         if (p >= r1 || o >= oc) return zero4();
-        return bn3_dp(tab, o, ld4(dout + (size_t)p * oc + o), ld4(Pr + ((size_t)g * Po + p) * oc + o));
+        return bn3_dp(tab, o, r.a, r.b);
     };
-    gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+    WGT(1)
+    gemm_mainloop2<NT, false, false>(la, xa, lb, xb, nchunks, acc, lds);
+    WGT(2)
     // The gradient is [oc][mc] (mid channel fastest) and a lane's accumulator quad is 4 consecutive mid channels of one
     // output channel: one 16-byte store per quad (the four lane groups of an output channel then cover 64 contiguous
     // bytes) instead of four 4-byte stores that each scatter a wave over 64 different cache lines.
@@ -341,6 +427,7 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
             }
         }
     }
+    WGT(3)
 }
 
 // ---------------------------------------------------------------------------- BN1-backward operand
@@ -382,7 +469,7 @@ __device__ __forceinline__ f32x4 sink_add(f32x4 v, float w, f32x4 g) {
 // K (up to 6912) is split over blockIdx.z when the output grid alone cannot fill the chip (7x7 / 14x14 cells: 49..196 row
 // tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them (and b, and the residual term).
 template <int NT>
-__global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ x, const float* __restrict__ cb1,
                                                       const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
@@ -409,7 +496,6 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
         sumw = 0.f;
         for (int g = 0; g < d.G; ++g) sumw += wmix[g];
     }
-    const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
@@ -430,23 +516,48 @@ __global__ __launch_bounds__(256, NT >= 5 ? 3 : 4) void k_expand_dgrad(TfnasCell
             }
             k0 = c * 16;
         };
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
+        auto la = [&](int c, int row, int kl) -> f32x4 {
+            int g, k0;
+            locate(c, g, k0);
+            const int p = min(rt * 128 + row, P - 1), k = k0 + kl, gi = max(g, 0);
+            if (TFNAS_STOR(d.stor)) {        // bf16 dEh and fp32 x are different load widths
+                if (g < 0) return ld4(x + (size_t)p * ic + min(k, ic - 4));
+                return ldS4_raw(dEh, (size_t)p * M + d.g[gi].off + min(k, d.g[gi].mcp - 4), 1);
+            }
+            const float* src = g < 0 ? x : dEh + d.g[gi].off;          // wave-uniform selects, one unconditional load
+            const int ld = g < 0 ? ic : M, klim = g < 0 ? ic : d.g[gi].mcp;
+            return ld4(src + (size_t)p * ld + min(k, klim - 4));
+        };
+        auto xa = [&](f32x4 r, int c, int row, int kl) -> f32x4 {
             int g, k0;
             locate(c, g, k0);
             const int p = rt * 128 + row, k = k0 + kl;
             if (p >= P) return zero4();
-            if (g < 0) return k < ic ? ld4(x + (size_t)p * ic + k) : zero4();
-            return k < d.g[g].mcp ? ldS4(dEh, (size_t)p * M + d.g[g].off + k, d.stor) : zero4();
+            if (g < 0) return k < ic ? r : zero4();
+            return k < d.g[g].mcp ? ldS4_fin(r, d.stor) : zero4();
         };
-        auto fb = [&](int c, int kl, int n) -> f32x4 {
+        auto lb = [&](int c, int kl, int n) -> RawWS {
+            int g, k0;
+            locate(c, g, k0);
+            const int k = k0 + kl, col = min(n0 + n, ic - 4), gi = max(g, 0);
+            const float* src = g < 0 ? gram : d.g[gi].w_expand;
+            const int kc = min(k, (g < 0 ? ic : d.g[gi].mc) - 1);
+            RawWS r;
+            r.w = ld4(src + (size_t)kc * ic + col);
+            r.s = cb1[4 * (size_t)(g < 0 ? 0 : d.g[gi].off + kc) + 1];   // rstd only: a dword load (a quad whose other lanes
+                                                                         // die lets their registers be reused before the MFMAs
+                                                                         // -> a wait); ignored for the -G chunks
+            return r;
+        };
+        auto xb = [&](RawWS r, int c, int kl, int n) -> f32x4 {
             int g, k0;
             locate(c, g, k0);
             const int k = k0 + kl;
             if (n0 + n >= ic) return zero4();
-            if (g < 0) return k < ic ? -ld4(gram + (size_t)k * ic + n0 + n) : zero4();
-            return k < d.g[g].mc ? splat4(cb[d.g[g].off + k].y) * ld4(d.g[g].w_expand + (size_t)k * ic + n0 + n) : zero4();
+            if (g < 0) return k < ic ? -r.w : zero4();
+            return k < d.g[g].mc ? splat4(r.s) * r.w : zero4();
         };
-        gemm_mainloop<NT, true, false>(fa, fb, nchunks, acc, lds);
+        GEMM_AK(NT, false, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow, c = n0 + lc;
             if (p < P && c < ic) {
@@ -583,18 +694,32 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
 
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
-    auto fa = [&](int c, int kl, int m) -> f32x4 {
+    auto la = [&](int c, int kl, int m) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1), ch = min(m0 + m, mcp - 4);
+        const size_t at = (size_t)p * M + off + ch;
+        Raw2 r;
+        r.a = ldS4_raw(dEh, at, d.stor);
+        r.b = ldS4_raw(E, at, d.stor);
+        return r;
+    };
+    auto xa = [&](Raw2 r, int c, int kl, int m) -> f32x4 {
         const int p = r0 + c * 16 + kl, ch = m0 + m;
         if (p >= r1 || ch >= mcp) return zero4();
-        const size_t col = (size_t)off + ch;
-        return bn1_de(cb, ldS4(dEh, (size_t)p * M + col, d.stor), ldS4(E, (size_t)p * M + col, d.stor));
+        return bn1_de(cb, ldS4_fin(r.a, d.stor), ldS4_fin(r.b, d.stor));
     };
-    auto fb = [&](int c, int kl, int n) -> f32x4 {
+    auto lb = [&](int c, int kl, int n) -> f32x4 {
+        if (STEM) {
+            const int p = r0 + c * 16 + kl, cc = n0 + n;
+            return (p >= r1 || cc >= ic) ? zero4() : stem_patch4(x, d, p, cc);
+        }
+        const int p = min(r0 + c * 16 + kl, r1 - 1), cc = min(n0 + n, ic - 4);
+        return ld4(x + (size_t)p * ic + cc);
+    };
+    auto xb = [&](f32x4 r, int c, int kl, int n) -> f32x4 {
         const int p = r0 + c * 16 + kl, cc = n0 + n;
-        if (p >= r1 || cc >= ic) return zero4();
-        return STEM ? stem_patch4(x, d, p, cc) : ld4(x + (size_t)p * ic + cc);
+        return (p >= r1 || cc >= ic) ? zero4() : r;
     };
-    gemm_mainloop<NT, false, false>(fa, fb, nchunks, acc, lds);
+    gemm_mainloop2<NT, false, false>(la, xa, lb, xb, nchunks, acc, lds);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -664,7 +789,7 @@ static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30, int slo
     }
     return best;
 }
-static inline int gemm_slots(int nt) { return 256 * (nt >= 5 ? 3 : 4); }
+static inline int gemm_slots(int nt) { return 256 * (nt >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL); }
 
 // Column-tile width of the GEMMs whose N extent is the mid channels of EVERY group (tiles cannot straddle groups): the
 // candidate that pads the group widths least (72 | 144 -> 5 x 16: 960 columns for 864, where 4 x 16 needs 1280 and
@@ -787,6 +912,18 @@ static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
     return ((rps + 15) / 16) * 16;
 }
 
+// Under-filled launches (fewer workgroups than resident slots): ask for enough dynamic LDS that a CU cannot take more than
+// its even share ceil(wgs / 256) -- experiment knob TFNAS_SPREAD=1 (does the dispatcher pack CUs?)
+static size_t spread_lds(size_t shm, long wgs) {
+    static const char* e = getenv("TFNAS_SPREAD");
+    if (!e || e[0] != '1') return shm;
+    const long per_cu = (wgs + 255) / 256;
+    size_t want = (size_t)(160 * 1024) / (size_t)(per_cu > 0 ? per_cu : 1);
+    if (want > 64 * 1024) want = 64 * 1024;
+    want &= ~(size_t)255;
+    return want > shm ? want : shm;
+}
+
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s) {
@@ -801,7 +938,8 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
     const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G, out_size);
     dim3 grid(cdiv(Po, rps), mtiles, ntiles * d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
-        const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
+        size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
+        shm = spread_lds(shm, (long)grid.x * grid.y * grid.z);
         hipLaunchKernelGGL((k_project_wgrad<NT, ACT>), grid, dim3(256), shm, s, d, dout, Pr, D, gate, stats2,
                            stats3, red3, wmix, rps, ntiles, part, out_size);
     }))

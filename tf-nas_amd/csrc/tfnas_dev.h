@@ -19,16 +19,20 @@ static inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 
 // ----------------------------------------------------------------------------- activations
 // reference: Swish = x * sigmoid(x) (models/layers.py:26-35), ReLU (layers.py:470-471)
+// 1/(1+e^-x) through v_exp_f32 + v_rcp_f32 (1 ulp each).  An IEEE `/` costs ~10 more VALU instructions per element
+// (v_div_scale x2, fma chain, v_div_fmas, v_div_fixup), and the operand loaders that apply the activation are VALU-issue
+// bound: 682 VALU instructions per 32 MFMAs in k_project_fwd<4, swish> before this.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 template <int ACT>
 __device__ __forceinline__ float act_f(float x) {
     if (ACT == TFNAS_ACT_RELU) return fmaxf(x, 0.f);
-    return x / (1.f + __expf(-x));
+    return x * sigmoid_f(x);
 }
 // derivative w.r.t. the pre-activation x
 template <int ACT>
 __device__ __forceinline__ float act_d(float x) {
     if (ACT == TFNAS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
-    float s = 1.f / (1.f + __expf(-x));
+    const float s = sigmoid_f(x);
     return s * (1.f + x * (1.f - s));
 }
 template <int ACT>
@@ -43,7 +47,6 @@ __device__ __forceinline__ f32x4 act_d4(f32x4 v) {
     r.x = act_d<ACT>(v.x); r.y = act_d<ACT>(v.y); r.z = act_d<ACT>(v.z); r.w = act_d<ACT>(v.w);
     return r;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // ----------------------------------------------------------------------------- batch-norm constants
 // stats layout: [channel][2] doubles = (sum, sum of squares) over `cnt` elements.
@@ -101,6 +104,20 @@ __device__ __forceinline__ uint2 bf16x4_narrow(f32x4 v) {
 __device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int stor) {
     if (TFNAS_STOR(stor)) return bf16x4_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx));
     return ld4(base + idx);
+}
+// two-phase form for loaders that must not touch the loaded registers before the MFMAs (gemm_core.h): _raw only issues the
+// load (bf16: the 8 raw bytes travel in .x/.y), _fin widens
+__device__ __forceinline__ f32x4 ldS4_raw(const float* base, size_t idx, int stor) {
+    if (TFNAS_STOR(stor)) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        f32x4 r = {__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+        return r;
+    }
+    return ld4(base + idx);
+}
+__device__ __forceinline__ f32x4 ldS4_fin(f32x4 raw, int stor) {
+    if (TFNAS_STOR(stor)) return bf16x4_widen(make_uint2(__float_as_uint(raw.x), __float_as_uint(raw.y)));
+    return raw;
 }
 __device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int stor) {
     if (TFNAS_STOR(stor)) {
