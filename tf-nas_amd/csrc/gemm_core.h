@@ -150,13 +150,22 @@ __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, i
 // stored with its rows permuted the same way (k -> row (k & 3) * 4 + (k >> 2)) and read exactly as before.  That removes
 // the transposing scalar LDS stores of A (the bank-conflicted part of the staging), its fragment reads and half of the LDS
 // footprint; global access pattern (64-byte row pieces) and accumulator layout are unchanged.
-template <int NT, bool BKC, bool PF2, class LA, class XA, class LB, class XB>
-__device__ __forceinline__ void gemm_mainloop_adirect(LA& la, XA& xa, LB& lb, XB& xb, int nchunks, f32x4 (&acc)[2][NT],
-                                                      float* lds) {
+// (Prefetch distance 2 -- loads of chunk c+2 in flight across two MFMA phases -- was built and measured on top of this:
+//  slower everywhere, with and without relaxed launch bounds; the loop is VALU-issue bound in the loaders, not latency bound.)
+// Loader signatures here: la(c, i, kl) / xa(raw, c, i, kl) with i in {0, 1} = which of the lane's two rows
+// (row = wrow + 16 i + (lane & 15), fixed for the whole K loop -- kernels keep per-row pointers / flags in registers instead
+// of recomputing them per chunk) and kl = 4 (lane >> 4);  lb / xb as in gemm_mainloop2;  pre(c) runs once per chunk before
+// its loads are issued (chunk -> group bookkeeping shared by the four loader pieces).
+struct PreNone {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int NT, bool BKC, class PRE, class LA, class XA, class LB, class XB>
+__device__ __forceinline__ void gemm_mainloop_adirect(PRE& pre, LA& la, XA& xa, LB& lb, XB& xb, int nchunks,
+                                                      f32x4 (&acc)[2][NT], float* lds) {
     using T = GT<NT>;
     using RA = decltype(la(0, 0, 0));
     using RB = decltype(lb(0, 0, 0));
-    const int tid = threadIdx.x, lane = tid & 63, wrow = (tid >> 6) * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     RA ra[2];
     RB rb[T::B_ITERS];
@@ -167,7 +176,8 @@ __device__ __forceinline__ void gemm_mainloop_adirect(LA& la, XA& xa, LB& lb, XB
               b1_ = BKC ? (idx & 3) * 4 : (idx % (T::BN / 4)) * 4
 #define TFNAS_GLOAD(c)                                                                      \
     {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra[i] = la((c), wrow + 16 * i + lr, 4 * lk); \
+        pre(c);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra[i] = la((c), i, 4 * lk);           \
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
             TFNAS_B_IDX(i);                                                                 \
             if (idx < T::B_ITEMS) rb[i] = lb((c), b0_, b1_);                                \
@@ -175,7 +185,7 @@ __device__ __forceinline__ void gemm_mainloop_adirect(LA& la, XA& xa, LB& lb, XB
     }
 #define TFNAS_SSTORE(c, Bs)                                                                 \
     {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) cur[i] = xa(ra[i], (c), wrow + 16 * i + lr, 4 * lk); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) cur[i] = xa(ra[i], (c), i, 4 * lk);   \
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
             TFNAS_B_IDX(i);                                                                 \
             if (idx < T::B_ITEMS) {                                                         \
@@ -195,87 +205,31 @@ __device__ __forceinline__ void gemm_mainloop_adirect(LA& la, XA& xa, LB& lb, XB
 
     float* Bs0 = lds;
     float* Bs1 = lds + T::B_FLOATS;
-#define TFNAS_MFMAS(Bs)                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                      \
-        const int k = ks * 4 + lk;                                                          \
-        const float a0 = cur[0][ks], a1 = cur[1][ks];                                       \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                    \
-            const float b = (Bs)[k * T::LDB + 16 * j + lr];                                 \
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);    \
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);    \
-        }                                                                                   \
+    if (nchunks > 0) {
+        TFNAS_GLOAD(0);
+        TFNAS_SSTORE(0, Bs0);
     }
-    if (PF2) {
-        // prefetch distance 2: the loads of chunk c+2 are issued before the MFMAs of chunk c and consumed after the MFMAs
-        // of chunk c+1 -- one chunk of MFMAs (0.2-0.75 us per wave) is shorter than a loaded-HBM round trip (1-2 us), and
-        // the 2-3.5 resident waves per SIMD these launches reach do not cover the difference.  Two raw register sets,
-        // alternating statically (loop unrolled by two).
-        RA ra2[2];
-        RB rb2[T::B_ITERS];
-#define TFNAS_GLOAD2(c)                                                                     \
-    {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra2[i] = la((c), wrow + 16 * i + lr, 4 * lk); \
-        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
-            TFNAS_B_IDX(i);                                                                 \
-            if (idx < T::B_ITEMS) rb2[i] = lb((c), b0_, b1_);                               \
-        }                                                                                   \
-    }
-#define TFNAS_SSTORE2(c, Bs)                                                                \
-    {                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) cur[i] = xa(ra2[i], (c), wrow + 16 * i + lr, 4 * lk); \
-        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
-            TFNAS_B_IDX(i);                                                                 \
-            if (idx < T::B_ITEMS) {                                                         \
-                const f32x4 v = xb(rb2[i], (c), b0_, b1_);                                  \
-                if (BKC) {                                                                  \
-                    const int r0_ = b1_ >> 2;                                               \
-                    (Bs)[(r0_ + 0) * T::LDB + b0_] = v.x;                                   \
-                    (Bs)[(r0_ + 4) * T::LDB + b0_] = v.y;                                   \
-                    (Bs)[(r0_ + 8) * T::LDB + b0_] = v.z;                                   \
-                    (Bs)[(r0_ + 12) * T::LDB + b0_] = v.w;                                  \
-                } else {                                                                    \
-                    st4(&(Bs)[((b0_ & 3) * 4 + (b0_ >> 2)) * T::LDB + b1_], v);             \
-                }                                                                           \
-            }                                                                               \
-        }                                                                                   \
-    }
-        if (nchunks > 0) {
-            TFNAS_GLOAD(0);
-            TFNAS_SSTORE(0, Bs0);
-        }
-        if (nchunks > 1) TFNAS_GLOAD2(1);
-        __syncthreads();
-        for (int c = 0; c < nchunks; c += 2) {
-            if (c + 2 < nchunks) TFNAS_GLOAD(c + 2);
-            TFNAS_MFMAS(Bs0);
-            if (c + 1 < nchunks) TFNAS_SSTORE2(c + 1, Bs1);
-            __syncthreads();
-            if (c + 1 >= nchunks) break;
-            if (c + 3 < nchunks) TFNAS_GLOAD2(c + 3);
-            TFNAS_MFMAS(Bs1);
-            if (c + 2 < nchunks) TFNAS_SSTORE(c + 2, Bs0);
-            __syncthreads();
-        }
-#undef TFNAS_GLOAD2
-#undef TFNAS_SSTORE2
-    } else {
-        if (nchunks > 0) {
-            TFNAS_GLOAD(0);
-            TFNAS_SSTORE(0, Bs0);
-        }
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const float* Bs = (c & 1) ? Bs1 : Bs0;
-            const bool more = (c + 1 < nchunks);
-            if (more) TFNAS_GLOAD(c + 1);
-            TFNAS_MFMAS(Bs);
-            if (more) {
-                if (c & 1) { TFNAS_SSTORE(c + 1, Bs0); } else { TFNAS_SSTORE(c + 1, Bs1); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* Bs = (c & 1) ? Bs1 : Bs0;
+        const bool more = (c + 1 < nchunks);
+        if (more) TFNAS_GLOAD(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 4 + lk;
+            const float a0 = cur[0][ks], a1 = cur[1][ks];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float b = Bs[k * T::LDB + 16 * j + lr];
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
             }
-            __syncthreads();
         }
+        if (more) {
+            if (c & 1) { TFNAS_SSTORE(c + 1, Bs0); } else { TFNAS_SSTORE(c + 1, Bs1); }
+        }
+        __syncthreads();
     }
-#undef TFNAS_MFMAS
 #undef TFNAS_GLOAD
 #undef TFNAS_SSTORE
 #undef TFNAS_B_IDX

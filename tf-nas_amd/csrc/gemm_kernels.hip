@@ -28,14 +28,6 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
     return v;
 }
 
-// main loop of the GEMMs whose A operand is K-contiguous: A straight into the MFMA lanes (build with -DTFNAS_A_STAGED for the
-// LDS-staged loop of rounds 1-2, A/B measurements)
-#ifdef TFNAS_A_STAGED
-#define GEMM_AK(NT, BKC, la, xa, lb, xb, n, acc, lds) gemm_mainloop2<NT, true, BKC>(la, xa, lb, xb, n, acc, lds)
-#else
-#ifndef TFNAS_PF2
-#define TFNAS_PF2 false
-#endif
 // resident workgroups per CU the row-tiled GEMM kernels are compiled for (register cap 512 / n per lane): 5-/7-tile and
 // narrower variants
 #ifndef TFNAS_LB_BIG
@@ -43,8 +35,6 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
 #endif
 #ifndef TFNAS_LB_SMALL
 #define TFNAS_LB_SMALL 4
-#endif
-#define GEMM_AK(NT, BKC, la, xa, lb, xb, n, acc, lds) gemm_mainloop_adirect<NT, BKC, TFNAS_PF2>(la, xa, lb, xb, n, acc, lds)
 #endif
 
 // -DTFNAS_WG_TIMING (tools/wg_timeline.py): per-workgroup wall-clock stamps (100 MHz s_memrealtime) of the weight-gradient
@@ -86,8 +76,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int n0 = ty * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7, nchunks = (ic + 15) >> 4;
-    const int tid = threadIdx.x;
-    (void)tid;
+    const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
 
     float cs[NT], cq[NT];
 #pragma unroll
@@ -96,17 +85,34 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int p = rt * 128 + row, k = c * 16 + kl;
-            if (p >= P || k >= ic) return zero4();
-            return STEM ? stem_patch4(x, d, p, k) : ld4(x + (size_t)p * ic + k);
+        // the lane's two A rows stay the same for the whole K loop: row pointers and validity live in registers
+        int prow[2];
+        const float* arow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            prow[i] = rt * 128 + wrow + 16 * i + lr;
+            arow[i] = x + (size_t)min(prow[i], P - 1) * ic;
+        }
+        auto la = [&](int c, int i, int kl) -> f32x4 {
+            const int k = c * 16 + kl;
+            if (STEM) return (prow[i] < P && k < ic) ? stem_patch4(x, d, prow[i], k) : zero4();
+            return ld4(arow[i] + min(k, ic - 4));
         };
-        auto fb = [&](int c, int n, int kl) -> f32x4 {
+        auto xa = [&](f32x4 r, int c, int i, int kl) -> f32x4 {
+            if (STEM) return r;
+            return (prow[i] < P && c * 16 + kl < ic) ? r : zero4();
+        };
+        auto lb = [&](int c, int n, int kl) -> f32x4 {
             const int col = n0 + n, k = c * 16 + kl;
-            return (col < mc) ? ld4_guard(w + (size_t)col * ic, k, ic, !STEM) : zero4();
+            if (STEM) return (col < mc) ? ld4_guard(w + (size_t)col * ic, k, ic, false) : zero4();
+            return ld4(w + (size_t)min(col, mc - 1) * ic + min(k, ic - 4));        // ic % 4 == 0: k < ic <=> k + 3 < ic
         };
-        XfId id;
-        GEMM_AK(NT, true, fa, id, fb, id, nchunks, acc, lds);
+        auto xb = [&](f32x4 r, int c, int n, int kl) -> f32x4 {
+            if (STEM) return r;
+            return (n0 + n < mc && c * 16 + kl < ic) ? r : zero4();
+        };
+        PreNone pre;
+        gemm_mainloop_adirect<NT, true>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < P && n0 + lc < mcp) stS4_nt(E, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int per = (nchunks_all + nsplit - 1) / nsplit, cb = ks * per;
     const int nchunks = max(0, min(nchunks_all, cb + per) - cb);
     float* __restrict__ dst = ks == 0 ? Pr : prp + (size_t)(ks - 1) * d.G * Po * oc;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
 
     float2* cst = reinterpret_cast<float2*>(lds + T::LDS_FLOATS);
     for (int c = tid; c < ((mcp + 15) & ~15); c += 256)
@@ -165,31 +171,47 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        auto la = [&](int c, int row, int kl) -> Raw2 {
-            const int p = min(rt * 128 + row, Po - 1), k = min((cb + c) * 16 + kl, mcp - 4);
+        // the lane's two A rows stay the same for the whole K loop: element offsets of the rows in D and in the gate table
+        // (one division per row tile instead of one per chunk) and validity live in registers
+        size_t arow[2], grow[2];
+        bool rok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = rt * 128 + wrow + 16 * i + lr, pc = min(p, Po - 1);
+            rok[i] = p < Po;
+            arow[i] = (size_t)pc * M + off;
+            grow[i] = ((size_t)(pc / HW) * M + off) * se01;
+        }
+        auto la = [&](int c, int i, int kl) -> Raw2 {
+            const int k = min((cb + c) * 16 + kl, mcp - 4);
             Raw2 r;
-            r.a = ldS4_raw(D, (size_t)p * M + off + k, d.stor);
-            r.b = ld4(gbase + ((size_t)(p / HW) * M + off + k) * se01);     // no SE: one fixed (ignored) quad
+            r.a = ldS4_raw(D, arow[i] + k, d.stor);
+            r.b = ld4(gbase + grow[i] + k * se01);                // no SE: one fixed (ignored) quad
             return r;
         };
-        auto xa = [&](Raw2 r, int c, int row, int kl) -> f32x4 {
-            const int p = rt * 128 + row, k = (cb + c) * 16 + kl;
-            if (p >= Po || k >= mcp) return zero4();
+        auto xa = [&](Raw2 r, int c, int i, int kl) -> f32x4 {
+            const int k = (cb + c) * 16 + kl;
             f32x4 v = ldS4_fin(r.a, d.stor);
-            const float2 c0 = cst[k], c1 = cst[k + 1], c2 = cst[k + 2], c3 = cst[k + 3];
+            const int kc = min(k, mcp - 4);
+            const float2 c0 = cst[kc], c1 = cst[kc + 1], c2 = cst[kc + 2], c3 = cst[kc + 3];
             v.x = act_f<ACT>((v.x - c0.x) * c0.y);
             v.y = act_f<ACT>((v.y - c1.x) * c1.y);
             v.z = act_f<ACT>((v.z - c2.x) * c2.y);
             v.w = act_f<ACT>((v.w - c3.x) * c3.y);
             if (has_se) v *= r.b;
-            return v;
+            return (rok[i] && k < mcp) ? v : zero4();
         };
-        auto fb = [&](int c, int n, int kl) -> f32x4 {
+        auto lb = [&](int c, int n, int kl) -> f32x4 {
             const int o = n0 + n, k = (cb + c) * 16 + kl;
-            return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, w_al) : zero4();
+            if (!w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, false) : zero4();
+            return ld4(w + (size_t)min(o, oc - 1) * mc + min(k, mc - 4));          // mc % 4 == 0: k < mc <=> k + 3 < mc
         };
-        XfId id;
-        GEMM_AK(NT, true, la, xa, fb, id, nchunks, acc, lds);
+        auto xb = [&](f32x4 r, int c, int n, int kl) -> f32x4 {
+            if (!w_al) return r;
+            return (n0 + n < oc && (cb + c) * 16 + kl < mc) ? r : zero4();
+        };
+        PreNone pre;
+        gemm_mainloop_adirect<NT, true>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < oc) st4(dst + ((size_t)g * Po + p) * oc + n0 + lc, v);
@@ -298,8 +320,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int Po = d.N * d.Ho * d.Wo, oc = d.oc, M = d.M;
     const int ocp = (oc + 15) & ~15;
     const int nrt = (Po + 127) >> 7, nchunks = ocp >> 4;
-    const int tid = threadIdx.x;
-    (void)tid;
+    const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
     __syncthreads();
@@ -307,24 +328,39 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        auto la = [&](int c, int row, int kl) -> Raw2 {
-            const int p = min(rt * 128 + row, Po - 1), o = min(c * 16 + kl, oc - 4);
+        const float* drow[2];
+        const float* qrow[2];
+        bool rok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = rt * 128 + wrow + 16 * i + lr, pc = min(p, Po - 1);
+            rok[i] = p < Po;
+            drow[i] = dout + (size_t)pc * oc;
+            qrow[i] = Pr + ((size_t)g * Po + pc) * oc;
+        }
+        auto la = [&](int c, int i, int kl) -> Raw2 {
+            const int o = min(c * 16 + kl, oc - 4);
             Raw2 r;
-            r.a = ld4(dout + (size_t)p * oc + o);
-            r.b = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+            r.a = ld4(drow[i] + o);
+            r.b = ld4(qrow[i] + o);
             return r;
         };
-        auto xa = [&](Raw2 r, int c, int row, int kl) -> f32x4 {
-            const int p = rt * 128 + row, o = c * 16 + kl;
-            if (p >= Po || o >= oc) return zero4();
-            return bn3_dp(tab, o, r.a, r.b);
-        };
-        auto fb = [&](int c, int kl, int n) -> f32x4 {
+        auto xa = [&](Raw2 r, int c, int i, int kl) -> f32x4 {
             const int o = c * 16 + kl;
-            return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, w_al) : zero4();
+            const f32x4 v = bn3_dp(tab, min(o, oc - 4), r.a, r.b);
+            return (rok[i] && o < oc) ? v : zero4();
         };
-        XfId id;
-        GEMM_AK(NT, false, la, xa, fb, id, nchunks, acc, lds);
+        auto lb = [&](int c, int kl, int n) -> f32x4 {
+            const int o = c * 16 + kl;
+            if (!w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, false) : zero4();
+            return ld4(w + (size_t)min(o, oc - 1) * mc + min(n0 + n, mc - 4));
+        };
+        auto xb = [&](f32x4 r, int c, int kl, int n) -> f32x4 {
+            if (!w_al) return r;
+            return (c * 16 + kl < oc && n0 + n < mc) ? r : zero4();
+        };
+        PreNone pre;
+        gemm_mainloop_adirect<NT, false>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -481,6 +517,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int n0 = blockIdx.y * T::BN;
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7;
+    const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
     int mchunks = 0;
     for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
     const int nchunks_all = mchunks + ((ic + 15) >> 4);      // mid-channel chunks, then the x / -G chunks
@@ -500,64 +537,67 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
         acc_zero<NT>(acc);
-        // chunk -> (group, first channel); g = -1: chunk of the x / -G part, k0 = first input channel
-        auto locate = [&](int c, int& g, int& k0) {
+        // chunk -> operand sources, worked out once per chunk (pre) for the four loader pieces: mid-channel chunks of
+        // group g read dEh / rstd-scaled W_g, the trailing chunks read x / -G
+        bool is_x;                       // chunk of the x / -G part
+        int k0, klim_a, klim_b, ld_a;    // first k of the chunk; valid k of A (mcp | ic) and of B (mc | ic); A row stride
+        size_t aoff;                     // element offset of the group's columns in a dEh row
+        const float* bsrc;               // W_g or G
+        const float* ssrc;               // rstd of the group's channels (cb1[...].y), stride 4
+        auto pre = [&](int c) {
             c += cbeg;
             if (c >= mchunks) {
-                g = -1;
+                is_x = true;
                 k0 = (c - mchunks) * 16;
+                klim_a = klim_b = ld_a = ic;
+                aoff = 0;
+                bsrc = gram;
+                ssrc = cb1 + 1;
                 return;
             }
-            g = 0;
+            int g = 0;
             for (; g < d.G - 1; ++g) {
                 const int t = (d.g[g].mcp + 15) >> 4;
                 if (c < t) break;
                 c -= t;
             }
+            is_x = false;
             k0 = c * 16;
+            klim_a = d.g[g].mcp;
+            klim_b = d.g[g].mc;
+            ld_a = M;
+            aoff = d.g[g].off;
+            bsrc = d.g[g].w_expand;
+            ssrc = cb1 + 4 * (size_t)d.g[g].off + 1;
         };
-        auto la = [&](int c, int row, int kl) -> f32x4 {
-            int g, k0;
-            locate(c, g, k0);
-            const int p = min(rt * 128 + row, P - 1), k = k0 + kl, gi = max(g, 0);
+        int prow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) prow[i] = rt * 128 + wrow + 16 * i + lr;
+        auto la = [&](int c, int i, int kl) -> f32x4 {
+            const int pc = min(prow[i], P - 1), k = min(k0 + kl, klim_a - 4);
             if (TFNAS_STOR(d.stor)) {        // bf16 dEh and fp32 x are different load widths
-                if (g < 0) return ld4(x + (size_t)p * ic + min(k, ic - 4));
-                return ldS4_raw(dEh, (size_t)p * M + d.g[gi].off + min(k, d.g[gi].mcp - 4), 1);
+                if (is_x) return ld4(x + (size_t)pc * ic + k);
+                return ldS4_raw(dEh, (size_t)pc * M + aoff + k, 1);
             }
-            const float* src = g < 0 ? x : dEh + d.g[gi].off;          // wave-uniform selects, one unconditional load
-            const int ld = g < 0 ? ic : M, klim = g < 0 ? ic : d.g[gi].mcp;
-            return ld4(src + (size_t)p * ld + min(k, klim - 4));
+            return ld4((is_x ? x : dEh) + (size_t)pc * ld_a + aoff + k);       // wave-uniform select, one unconditional load
         };
-        auto xa = [&](f32x4 r, int c, int row, int kl) -> f32x4 {
-            int g, k0;
-            locate(c, g, k0);
-            const int p = rt * 128 + row, k = k0 + kl;
-            if (p >= P) return zero4();
-            if (g < 0) return k < ic ? r : zero4();
-            return k < d.g[g].mcp ? ldS4_fin(r, d.stor) : zero4();
+        auto xa = [&](f32x4 r, int c, int i, int kl) -> f32x4 {
+            const f32x4 v = (TFNAS_STOR(d.stor) && !is_x) ? ldS4_fin(r, 1) : r;
+            return (prow[i] < P && k0 + kl < klim_a) ? v : zero4();
         };
         auto lb = [&](int c, int kl, int n) -> RawWS {
-            int g, k0;
-            locate(c, g, k0);
-            const int k = k0 + kl, col = min(n0 + n, ic - 4), gi = max(g, 0);
-            const float* src = g < 0 ? gram : d.g[gi].w_expand;
-            const int kc = min(k, (g < 0 ? ic : d.g[gi].mc) - 1);
+            const int kc = min(k0 + kl, klim_b - 1), col = min(n0 + n, ic - 4);
             RawWS r;
-            r.w = ld4(src + (size_t)kc * ic + col);
-            r.s = cb1[4 * (size_t)(g < 0 ? 0 : d.g[gi].off + kc) + 1];   // rstd only: a dword load (a quad whose other lanes
-                                                                         // die lets their registers be reused before the MFMAs
-                                                                         // -> a wait); ignored for the -G chunks
+            r.w = ld4(bsrc + (size_t)kc * ic + col);
+            r.s = ssrc[is_x ? 0 : 4 * (size_t)kc];      // rstd only: a dword load (a quad whose other lanes die lets their
+                                                        // registers be reused before the MFMAs -> a wait); ignored for -G
             return r;
         };
         auto xb = [&](RawWS r, int c, int kl, int n) -> f32x4 {
-            int g, k0;
-            locate(c, g, k0);
-            const int k = k0 + kl;
-            if (n0 + n >= ic) return zero4();
-            if (g < 0) return k < ic ? -r.w : zero4();
-            return k < d.g[g].mc ? splat4(r.s) * r.w : zero4();
+            const f32x4 v = is_x ? -r.w : splat4(r.s) * r.w;
+            return (n0 + n < ic && k0 + kl < klim_b) ? v : zero4();
         };
-        GEMM_AK(NT, false, la, xa, lb, xb, nchunks, acc, lds);
+        gemm_mainloop_adirect<NT, false>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow, c = n0 + lc;
             if (p < P && c < ic) {
