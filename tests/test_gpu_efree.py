@@ -59,6 +59,16 @@ def test_efree_matches_e_path(case, idxs):
         if a is None:
             continue
         err, ref = hc.err(a, b)
+        if act == 'relu' and name == 'dx':
+            # The two routes sum the expand convolution in different orders, so a pre-activation within rounding noise of 0
+            # can land on either side of relu'(0) (tests/_hipcheck.py::relu_kink_masks): a handful of isolated dx pixels
+            # may then differ by O(1) while everything else agrees.  Bound their number and size, keep the gate elsewhere.
+            d = (a - b).abs().float().cpu()
+            tol = 2e-5 + 2e-4 * ref
+            bad = d > tol
+            assert int(bad.sum()) <= max(4, int(2e-5 * d.numel())) * ic, (name, int(bad.sum()), d.numel())
+            assert float(d.max()) <= 2.0 * ref and float(d.pow(2).sum().sqrt() / b.float().cpu().pow(2).sum().sqrt()) <= 2e-3
+            continue
         assert err <= 2e-5 + 2e-4 * ref, (name, err, ref)
 
 

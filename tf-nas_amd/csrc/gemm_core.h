@@ -39,22 +39,27 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[2][NT]) {
 }
 
 struct XfId {   // transform of a one-piece loader: the value is already final
-    __device__ __forceinline__ f32x4 operator()(f32x4 v, int, int, int) const { return v; }
+    __device__ __forceinline__ f32x4 operator()(f32x4 v, int, int, int, int) const { return v; }
 };
 
-// Two-phase operand loaders.  `la(c, i0, i1)` / `lb(c, i0, i1)` only ISSUE the global loads of K-chunk c and return the raw
-// registers (any struct); `xa(raw, c, i0, i1)` / `xb(...)` turn them into the f32x4 that goes to LDS (normalise, activate,
+// Two-phase operand loaders.  `la(c, i, i0, i1)` / `lb(c, i, i0, i1)` only ISSUE the global loads of K-chunk c and return the
+// raw registers (any struct); i = which of the thread's items (0..1 for A, 0..B_ITERS-1 for B; (i0, i1) of item i are the
+// same for every chunk, so kernels keep per-item pointers / constants in registers);
+// `xa(raw, c, i, i0, i1)` / `xb(...)` turn them into the f32x4 that goes to LDS (normalise, activate,
 // mask rows / columns outside the problem).  The split matters: the loads of chunk c+1 are issued before the MFMAs of chunk
 // c and must not be waited for until after them.  With a one-piece loader whose element-wise math sits in the same
 // conditional region as its load, the compiler put `s_waitcnt vmcnt(0)` straight after every load -- 2 to 5 serialized DRAM
 // round trips per K-chunk in front of the MFMAs (ISA of round 1/2's k_project_* / k_expand_dgrad / k_*_wgrad).  Loaders
 // therefore load unconditionally from clamped addresses and mask in the transform.
-template <int NT, bool AK, bool BKC, class LA, class XA, class LB, class XB>
+// BGUARD = false: lb is also called for item slots past the B tile (threads idx >= B_ITEMS; its result is dropped) -- the
+// kernel's lb must then be safe for any (i0, i1).  A load inside the divergent `if (idx < B_ITEMS)` region got an
+// s_waitcnt vmcnt(0) right behind it (the 5- and 7-tile variants, whose second B item covers only part of the threads).
+template <int NT, bool AK, bool BKC, bool BGUARD = true, class LA, class XA, class LB, class XB>
 __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, int nchunks, f32x4 (&acc)[2][NT],
                                                float* lds) {
     using T = GT<NT>;
-    using RA = decltype(la(0, 0, 0));
-    using RB = decltype(lb(0, 0, 0));
+    using RA = decltype(la(0, 0, 0, 0));
+    using RB = decltype(lb(0, 0, 0, 0));
     const int tid = threadIdx.x, lane = tid & 63, wrow = (tid >> 6) * 32;
     const int lr = lane & 15, lk = lane >> 4;
     RA ra[2];
@@ -68,18 +73,18 @@ __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, i
     {                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
             TFNAS_A_IDX(i);                                                                 \
-            ra[i] = la((c), a0_, a1_);                                                      \
+            ra[i] = la((c), i, a0_, a1_);                                                      \
         }                                                                                   \
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
             TFNAS_B_IDX(i);                                                                 \
-            if (idx < T::B_ITEMS) rb[i] = lb((c), b0_, b1_);                                \
+            if (!BGUARD || idx < T::B_ITEMS) rb[i] = lb((c), i, b0_, b1_);                                \
         }                                                                                   \
     }
 #define TFNAS_SSTORE(c, As, Bs)                                                             \
     {                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
             TFNAS_A_IDX(i);                                                                 \
-            const f32x4 v = xa(ra[i], (c), a0_, a1_);                                       \
+            const f32x4 v = xa(ra[i], (c), i, a0_, a1_);                                       \
             if (AK) {                                                                       \
                 (As)[(a1_ + 0) * T::LDA + a0_] = v.x;                                       \
                 (As)[(a1_ + 1) * T::LDA + a0_] = v.y;                                       \
@@ -92,7 +97,7 @@ __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, i
         _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) {                            \
             TFNAS_B_IDX(i);                                                                 \
             if (idx < T::B_ITEMS) {                                                         \
-                const f32x4 v = xb(rb[i], (c), b0_, b1_);                                   \
+                const f32x4 v = xb(rb[i], (c), i, b0_, b1_);                                   \
                 if (BKC) {                                                                  \
                     (Bs)[(b1_ + 0) * T::LDB + b0_] = v.x;                                   \
                     (Bs)[(b1_ + 1) * T::LDB + b0_] = v.y;                                   \
@@ -239,8 +244,10 @@ __device__ __forceinline__ void gemm_mainloop_adirect(PRE& pre, LA& la, XA& xa, 
 // flight across the MFMAs (plain unconditional loads, small weight tiles).
 template <int NT, bool AK, bool BKC, class FA, class FB>
 __device__ __forceinline__ void gemm_mainloop(FA& fa, FB& fb, int nchunks, f32x4 (&acc)[2][NT], float* lds) {
+    auto la = [&](int c, int, int i0, int i1) -> f32x4 { return fa(c, i0, i1); };
+    auto lb = [&](int c, int, int i0, int i1) -> f32x4 { return fb(c, i0, i1); };
     XfId id;
-    gemm_mainloop2<NT, AK, BKC>(fa, id, fb, id, nchunks, acc, lds);
+    gemm_mainloop2<NT, AK, BKC>(la, id, lb, id, nchunks, acc, lds);
 }
 
 // Per-column sums of the accumulator tile (rows outside the problem contribute exact zeros because the

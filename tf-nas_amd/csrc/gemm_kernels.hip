@@ -400,47 +400,77 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
-    // this thread always stages the same 4 mid channels: keep their BN2 constants in registers
+    // A thread stages the same 4 mid channels (A) and the same 4 output channels per B item in every K-chunk; only the
+    // pixel advances (by 16 per chunk).  Everything that depends on the channel alone lives in registers: the loaders of
+    // this kernel are VALU-issue bound (200 VALU instructions per 16 MFMAs before this), not bandwidth bound.
     const int mch = m0 + (tid & 31) * 4;
+    const bool chok = mch < mcp;
+    const size_t acol = (size_t)off + min(mch, mcp - 4);
     float2 c2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         c2[j] = (mch + j < mc) ? bn_consts(stats2 + 2 * (size_t)(off + mch + j), 1.0 / (double)Po, d.eps)
                                : make_float2(0.f, 0.f);
     __syncthreads();
+    // BN3 backward with folded per-column constants:  dP = a3 (dOut - b3) - (Pr - mean) (rstd c3 a3)
+    constexpr int BQ = T::BN / 4;
+    int bcol[T::B_ITERS];
+    bool bok[T::B_ITERS];
+    f32x4 k_mean[T::B_ITERS], k_a3[T::B_ITERS], k_ab[T::B_ITERS], k_s[T::B_ITERS];
+#pragma unroll
+    for (int i = 0; i < T::B_ITERS; ++i) {
+        const int idx = tid + 256 * i, o = n0 + (idx % BQ) * 4;
+        bok[i] = idx < T::B_ITEMS && o < oc;
+        bcol[i] = min(o, oc - 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oo = bcol[i] + j;
+            k_mean[i][j] = tab.mean[oo];
+            k_a3[i][j] = tab.a3[oo];
+            k_ab[i][j] = tab.a3[oo] * tab.b3[oo];
+            k_s[i][j] = tab.rstd[oo] * tab.c3[oo] * tab.a3[oo];
+        }
+    }
+    const float inv_hw = 1.f / (float)HW;
+    const bool small_p = Po < (1 << 24);
+    auto image_of = [&](int p) -> int {       // p / HW without the 22-instruction integer division (exact for p < 2^24)
+        if (!small_p) return p / HW;
+        int q = (int)((float)p * inv_hw);
+        const int r = p - q * HW;
+        q += (r >= HW) ? 1 : 0;
+        q -= (r < 0) ? 1 : 0;
+        return q;
+    };
 
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
-    auto la = [&](int c, int kl, int m) -> Raw2 {
-        const int p = min(r0 + c * 16 + kl, r1 - 1), ch = min(m0 + m, mcp - 4);
+    auto la = [&](int c, int i, int kl, int m) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1);
         Raw2 r;
-        r.a = ldS4_raw(D, (size_t)p * M + off + ch, d.stor);
-        r.b = ld4(gbase + ((size_t)(p / HW) * M + off + ch) * se01);        // no SE: one fixed (ignored) quad
+        r.a = ldS4_raw(D, (size_t)p * M + acol, d.stor);
+        r.b = ld4(gbase + ((size_t)image_of(p) * M + acol) * se01);        // no SE: one fixed (ignored) quad
         return r;
     };
-    auto xa = [&](Raw2 r, int c, int kl, int m) -> f32x4 {
-        const int p = r0 + c * 16 + kl, ch = m0 + m;
-        if (p >= r1 || ch >= mcp) return zero4();
+    auto xa = [&](Raw2 r, int c, int i, int kl, int m) -> f32x4 {
         f32x4 v = ldS4_fin(r.a, d.stor);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_f<ACT>((v[j] - c2[j].x) * c2[j].y);
         if (has_se) v *= r.b;
-        return v;
+        return (chok && r0 + c * 16 + kl < r1) ? v : zero4();
     };
-    auto lb = [&](int c, int kl, int n) -> Raw2 {
-        const int p = min(r0 + c * 16 + kl, r1 - 1), o = min(n0 + n, oc - 4);
+    auto lb = [&](int c, int i, int kl, int n) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1);
         Raw2 r;
-        r.a = ld4(dout + (size_t)p * oc + o);
-        r.b = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+        r.a = ld4(dout + (size_t)p * oc + bcol[i]);
+        r.b = ld4(Pr + ((size_t)g * Po + p) * oc + bcol[i]);
         return r;
     };
-    auto xb = [&](Raw2 r, int c, int kl, int n) -> f32x4 {
-        const int p = r0 + c * 16 + kl, o = n0 + n;
-        if (p >= r1 || o >= oc) return zero4();
-        return bn3_dp(tab, o, r.a, r.b);
+    auto xb = [&](Raw2 r, int c, int i, int kl, int n) -> f32x4 {
+        const f32x4 v = (k_a3[i] * r.a - k_ab[i]) - (r.b - k_mean[i]) * k_s[i];
+        return (bok[i] && r0 + c * 16 + kl < r1) ? v : zero4();
     };
     WGT(1)
-    gemm_mainloop2<NT, false, false>(la, xa, lb, xb, nchunks, acc, lds);
+    gemm_mainloop2<NT, false, false, false>(la, xa, lb, xb, nchunks, acc, lds);
     WGT(2)
     // The gradient is [oc][mc] (mid channel fastest) and a lane's accumulator quad is 4 consecutive mid channels of one
     // output channel: one 16-byte store per quad (the four lane groups of an output channel then cover 64 contiguous
@@ -726,40 +756,57 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
 
+    // per-thread constants of the K loop (see k_project_wgrad): the thread's 4 mid channels and its BN1-backward constants,
+    // folded:  de = rstd (deh - t1 - (E - mu) rstd t2)  =  rstd deh - rstd t1 - (E - mu) (rstd^2 t2)
     const int mch = m0 + (tid & 31) * 4;
-    f32x4 cb[4];
+    const bool chok = mch < mcp;
+    const size_t acol = (size_t)off + min(mch, mcp - 4);
+    f32x4 k_mu, k_r, k_rt1, k_s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        cb[j] = (mch + j < mcp) ? reinterpret_cast<const f32x4*>(cb1)[off + mch + j] : zero4();
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = (mch + j < mcp) ? reinterpret_cast<const f32x4*>(cb1)[off + mch + j] : zero4();
+        k_mu[j] = t.x;
+        k_r[j] = t.y;
+        k_rt1[j] = t.y * t.z;
+        k_s[j] = t.y * t.y * t.w;
+    }
+    constexpr int BQ = T::BN / 4;
+    int bcol[T::B_ITERS];
+    bool bok[T::B_ITERS];
+#pragma unroll
+    for (int i = 0; i < T::B_ITERS; ++i) {
+        const int idx = tid + 256 * i, cc = n0 + (idx % BQ) * 4;
+        bok[i] = idx < T::B_ITEMS && cc < ic;
+        bcol[i] = STEM ? cc : min(cc, ic - 4);
+    }
 
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
-    auto la = [&](int c, int kl, int m) -> Raw2 {
-        const int p = min(r0 + c * 16 + kl, r1 - 1), ch = min(m0 + m, mcp - 4);
-        const size_t at = (size_t)p * M + off + ch;
+    auto la = [&](int c, int i, int kl, int m) -> Raw2 {
+        const int p = min(r0 + c * 16 + kl, r1 - 1);
+        const size_t at = (size_t)p * M + acol;
         Raw2 r;
         r.a = ldS4_raw(dEh, at, d.stor);
         r.b = ldS4_raw(E, at, d.stor);
         return r;
     };
-    auto xa = [&](Raw2 r, int c, int kl, int m) -> f32x4 {
-        const int p = r0 + c * 16 + kl, ch = m0 + m;
-        if (p >= r1 || ch >= mcp) return zero4();
-        return bn1_de(cb, ldS4_fin(r.a, d.stor), ldS4_fin(r.b, d.stor));
+    auto xa = [&](Raw2 r, int c, int i, int kl, int m) -> f32x4 {
+        const f32x4 v = (k_r * ldS4_fin(r.a, d.stor) - k_rt1) - (ldS4_fin(r.b, d.stor) - k_mu) * k_s;
+        return (chok && r0 + c * 16 + kl < r1) ? v : zero4();
     };
-    auto lb = [&](int c, int kl, int n) -> f32x4 {
+    auto lb = [&](int c, int i, int kl, int n) -> f32x4 {
         if (STEM) {
-            const int p = r0 + c * 16 + kl, cc = n0 + n;
-            return (p >= r1 || cc >= ic) ? zero4() : stem_patch4(x, d, p, cc);
+            const int p = r0 + c * 16 + kl;
+            return (p < r1 && bok[i]) ? stem_patch4(x, d, p, bcol[i]) : zero4();
         }
-        const int p = min(r0 + c * 16 + kl, r1 - 1), cc = min(n0 + n, ic - 4);
-        return ld4(x + (size_t)p * ic + cc);
+        const int p = min(r0 + c * 16 + kl, r1 - 1);
+        return ld4(x + (size_t)p * ic + bcol[i]);
     };
-    auto xb = [&](f32x4 r, int c, int kl, int n) -> f32x4 {
-        const int p = r0 + c * 16 + kl, cc = n0 + n;
-        return (p >= r1 || cc >= ic) ? zero4() : r;
+    auto xb = [&](f32x4 r, int c, int i, int kl, int n) -> f32x4 {
+        if (STEM) return r;
+        return (bok[i] && r0 + c * 16 + kl < r1) ? r : zero4();
     };
-    gemm_mainloop2<NT, false, false>(la, xa, lb, xb, nchunks, acc, lds);
+    gemm_mainloop2<NT, false, false, false>(la, xa, lb, xb, nchunks, acc, lds);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
