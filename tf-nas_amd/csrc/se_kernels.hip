@@ -52,73 +52,119 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
     f32x4 acc[2][NT];
     acc_zero<NT>(acc);
 
-    auto dgl4 = [&](int n, int ch) -> f32x4 {       // d loss / d (pre-sigmoid gate), 4 channels
-        const f32x4 gt = ld4(a.gate + (size_t)n * M + off + ch);
-        const f32x4 dg = ld4(a.dgate + (size_t)n * M + off + ch);
-        return dg * gt * (splat4(1.f) - gt);
-    };
-    auto h4 = [&](int n, int j) -> f32x4 { return act_f4<ACT>(ld4(a.hpre + (size_t)n * SE + so + j)); };
+    // Two-phase loaders (gemm_core.h): the load pieces read unconditionally from clamped addresses, the transforms mask.
+    // These launches are 1-20 workgroups walking 8-72 K-chunks back to back -- nothing else on the CU hides a wait that
+    // sits between a load and the MFMAs (the one-piece loaders had 2-3 serialized round trips per chunk there).
+    struct Pair { f32x4 a, b; };
+    const f32x4 one4 = splat4(1.f);
+    XfId id;
 
     if (MODE == 0) {
         if (r0 >= N || n0 >= se) return;
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = (cbase + c) * 16 + kl;
-            return (n < N && k < mcp) ? ld4(a.pooled + (size_t)n * M + off + k) : zero4();
+        auto la = [&](int c, int, int row, int kl) -> f32x4 {
+            const int n = min(r0 + row, N - 1), k = min((cbase + c) * 16 + kl, mcp - 4);
+            return ld4(a.pooled + (size_t)n * M + off + k);
         };
-        auto fb = [&](int c, int nn, int kl) -> f32x4 {
+        auto xa = [&](f32x4 v, int c, int, int row, int kl) -> f32x4 {
+            return (r0 + row < N && (cbase + c) * 16 + kl < mcp) ? v : zero4();
+        };
+        auto lb = [&](int c, int, int nn, int kl) -> f32x4 {
             const int j = n0 + nn, k = (cbase + c) * 16 + kl;
-            return (j < se) ? ld4_guard(d.g[g].w_se_r + (size_t)j * mc, k, mc, mc_al) : zero4();
+            if (!mc_al) return (j < se) ? ld4_guard(d.g[g].w_se_r + (size_t)j * mc, k, mc, false) : zero4();
+            return ld4(d.g[g].w_se_r + (size_t)min(j, se - 1) * mc + min(k, mc - 4));
+        };
+        auto xb = [&](f32x4 v, int c, int, int nn, int kl) -> f32x4 {
+            if (!mc_al) return v;
+            return (n0 + nn < se && (cbase + c) * 16 + kl < mc) ? v : zero4();
         };
         const int tot = (mcp + 15) >> 4;
-        gemm_mainloop<NT, true, true>(fa, fb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
+        gemm_mainloop2<NT, true, true>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 1) {
         if (r0 >= N || n0 >= mcp) return;
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = c * 16 + kl;
-            return (n < N && k < se) ? h4(n, k) : zero4();
+        auto la = [&](int c, int, int row, int kl) -> f32x4 {
+            const int n = min(r0 + row, N - 1), k = min(c * 16 + kl, se - 4);
+            return ld4(a.hpre + (size_t)n * SE + so + k);
         };
-        auto fb = [&](int c, int nn, int kl) -> f32x4 {
-            const int col = n0 + nn, k = c * 16 + kl;
-            return (col < mc && k < se) ? ld4(d.g[g].w_se_e + (size_t)col * se + k) : zero4();
+        auto xa = [&](f32x4 v, int c, int, int row, int kl) -> f32x4 {
+            return (r0 + row < N && c * 16 + kl < se) ? act_f4<ACT>(v) : zero4();
         };
-        gemm_mainloop<NT, true, true>(fa, fb, (se + 15) >> 4, acc, lds);
+        auto lb = [&](int c, int, int nn, int kl) -> f32x4 {
+            const int col = min(n0 + nn, mc - 1), k = min(c * 16 + kl, se - 4);
+            return ld4(d.g[g].w_se_e + (size_t)col * se + k);
+        };
+        auto xb = [&](f32x4 v, int c, int, int nn, int kl) -> f32x4 {
+            return (n0 + nn < mc && c * 16 + kl < se) ? v : zero4();
+        };
+        gemm_mainloop2<NT, true, true>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
     } else if (MODE == 2) {
         if (r0 >= N || n0 >= se) return;
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = (cbase + c) * 16 + kl;
-            return (n < N && k < mcp) ? dgl4(n, k) : zero4();
+        auto la = [&](int c, int, int row, int kl) -> Pair {
+            const int n = min(r0 + row, N - 1), k = min((cbase + c) * 16 + kl, mcp - 4);
+            Pair r;
+            r.a = ld4(a.gate + (size_t)n * M + off + k);
+            r.b = ld4(a.dgate + (size_t)n * M + off + k);
+            return r;
         };
-        auto fb = [&](int c, int kl, int nn) -> f32x4 {
-            const int k = (cbase + c) * 16 + kl, j = n0 + nn;
-            return (k < mc && j < se) ? ld4(d.g[g].w_se_e + (size_t)k * se + j) : zero4();
+        auto xa = [&](Pair r, int c, int, int row, int kl) -> f32x4 {
+            return (r0 + row < N && (cbase + c) * 16 + kl < mcp) ? r.b * r.a * (one4 - r.a) : zero4();
+        };
+        auto lb = [&](int c, int, int kl, int nn) -> f32x4 {
+            const int k = min((cbase + c) * 16 + kl, mc - 1), j = min(n0 + nn, se - 4);
+            return ld4(d.g[g].w_se_e + (size_t)k * se + j);
+        };
+        auto xb = [&](f32x4 v, int c, int, int kl, int nn) -> f32x4 {
+            return ((cbase + c) * 16 + kl < mc && n0 + nn < se) ? v : zero4();
         };
         const int tot = (mcp + 15) >> 4;
-        gemm_mainloop<NT, true, false>(fa, fb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
+        gemm_mainloop2<NT, true, false>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 3) {
         if (r0 >= N || n0 >= mcp) return;
-        auto fa = [&](int c, int row, int kl) -> f32x4 {
-            const int n = r0 + row, k = c * 16 + kl;
-            return (n < N && k < se) ? ld4(a.dhpre + (size_t)n * SE + so + k) : zero4();
+        auto la = [&](int c, int, int row, int kl) -> f32x4 {
+            const int n = min(r0 + row, N - 1), k = min(c * 16 + kl, se - 4);
+            return ld4(a.dhpre + (size_t)n * SE + so + k);
         };
-        auto fb = [&](int c, int kl, int nn) -> f32x4 {
+        auto xa = [&](f32x4 v, int c, int, int row, int kl) -> f32x4 {
+            return (r0 + row < N && c * 16 + kl < se) ? v : zero4();
+        };
+        auto lb = [&](int c, int, int kl, int nn) -> f32x4 {
             const int k = c * 16 + kl;
-            return (k < se) ? ld4_guard(d.g[g].w_se_r + (size_t)k * mc, n0 + nn, mc, mc_al) : zero4();
+            if (!mc_al) return (k < se) ? ld4_guard(d.g[g].w_se_r + (size_t)k * mc, n0 + nn, mc, false) : zero4();
+            return ld4(d.g[g].w_se_r + (size_t)min(k, se - 1) * mc + min(n0 + nn, mc - 4));
         };
-        gemm_mainloop<NT, true, false>(fa, fb, (se + 15) >> 4, acc, lds);
+        auto xb = [&](f32x4 v, int c, int, int kl, int nn) -> f32x4 {
+            if (!mc_al) return v;
+            return (c * 16 + kl < se && n0 + nn < mc) ? v : zero4();
+        };
+        gemm_mainloop2<NT, true, false>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
     } else {   // MODE 4 / 5: rows = mid channels, cols = se, K = batch
         if (r0 >= mcp || n0 >= se) return;
-        auto fa = [&](int c, int kl, int m) -> f32x4 {
-            const int n = c * 16 + kl, ch = r0 + m;
-            if (n >= N || ch >= mcp) return zero4();
-            return MODE == 4 ? dgl4(n, ch) : ld4(a.pooled + (size_t)n * M + off + ch);
+        auto la = [&](int c, int, int kl, int m) -> Pair {
+            const int n = min(c * 16 + kl, N - 1), ch = min(r0 + m, mcp - 4);
+            Pair r;
+            if (MODE == 4) {
+                r.a = ld4(a.gate + (size_t)n * M + off + ch);
+                r.b = ld4(a.dgate + (size_t)n * M + off + ch);
+            } else {
+                r.a = ld4(a.pooled + (size_t)n * M + off + ch);
+                r.b = r.a;
+            }
+            return r;
         };
-        auto fb = [&](int c, int kl, int nn) -> f32x4 {
-            const int n = c * 16 + kl, j = n0 + nn;
-            if (n >= N || j >= se) return zero4();
-            return MODE == 4 ? h4(n, j) : ld4(a.dhpre + (size_t)n * SE + so + j);
+        auto xa = [&](Pair r, int c, int, int kl, int m) -> f32x4 {
+            const f32x4 v = MODE == 4 ? r.b * r.a * (one4 - r.a) : r.a;
+            return (c * 16 + kl < N && r0 + m < mcp) ? v : zero4();
         };
-        gemm_mainloop<NT, false, false>(fa, fb, (N + 15) >> 4, acc, lds);
+        auto lb = [&](int c, int, int kl, int nn) -> f32x4 {
+            const int n = min(c * 16 + kl, N - 1), j = min(n0 + nn, se - 4);
+            return ld4((MODE == 4 ? a.hpre : a.dhpre) + (size_t)n * SE + so + j);
+        };
+        auto xb = [&](f32x4 v, int c, int, int kl, int nn) -> f32x4 {
+            const f32x4 w = MODE == 4 ? act_f4<ACT>(v) : v;
+            return (c * 16 + kl < N && n0 + nn < se) ? w : zero4();
+        };
+        gemm_mainloop2<NT, false, false>(la, xa, lb, xb, (N + 15) >> 4, acc, lds);
     }
+    (void)id;
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
