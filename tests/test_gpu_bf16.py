@@ -78,9 +78,9 @@ def test_cell_bf16_storage_close_to_fp32(geom):
 def test_bf16_workspace_is_half_size():
     import ctypes as C
     from tfnas_amd import _lib
-    lib = _lib.lib(bf16=True)
     sizes = []
     for stor in (0, 1):
+        lib = _lib.lib(bf16=bool(stor))      # each library is compiled for ONE storage mode (csrc/Makefile)
         d = _lib.TfnasCellDesc()
         d.N, d.H, d.W, d.ic, d.oc, d.stride, d.act, d.G, d.eps, d.stor = 4, 28, 28, 40, 40, 1, 1, 2, 1e-5, stor
         d.has_res = 1
@@ -95,6 +95,8 @@ def test_bf16_workspace_is_half_size():
     assert sizes[1][4:] == sizes[0][4:]
     d.stor = 2
     assert lib.tfnas_cell_plan(C.byref(d)) != 0
+    d.stor = 0
+    assert lib.tfnas_cell_plan(C.byref(d)) == -1                 # the bf16 library takes stor = 1 only
     d.stor = 1
     assert lib.tfnas_has_bf16_storage() == 1 and _lib.lib().tfnas_has_bf16_storage() == 0
     assert _lib.lib().tfnas_cell_plan(C.byref(d)) == -1          # the product library is the fp32-only build: TFNAS_EINVAL

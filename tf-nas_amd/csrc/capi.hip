@@ -135,6 +135,9 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
 #ifdef TFNAS_NO_BF16
     if (d->stor) return TFNAS_EINVAL;         // this build has the bf16-storage branches compiled out (see Makefile)
 #endif
+#ifdef TFNAS_ONLY_BF16
+    if (!d->stor) return TFNAS_EINVAL;        // ... and this one the fp32-storage branches: MixedOP cells with stor = 1 only
+#endif
     if (d->stor && d->mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;      // bf16 storage: MixedOP cells only (stems / head keep fp32)
     if (d->N < 1 || d->H < 1 || d->W < 1 || d->oc < 4 || (d->oc & 3)) return TFNAS_EINVAL;
     if (d->oc > 1024) return TFNAS_EINVAL;

@@ -54,7 +54,7 @@ struct XfId {   // transform of a one-piece loader: the value is already final
 // BGUARD = false: lb is also called for item slots past the B tile (threads idx >= B_ITEMS; its result is dropped) -- the
 // kernel's lb must then be safe for any (i0, i1).  A load inside the divergent `if (idx < B_ITEMS)` region got an
 // s_waitcnt vmcnt(0) right behind it (the 5- and 7-tile variants, whose second B item covers only part of the threads).
-template <int NT, bool AK, bool BKC, bool BGUARD = true, class LA, class XA, class LB, class XB>
+template <int NT, bool AK, bool BKC, bool BGUARD = true, bool PF2 = false, class LA, class XA, class LB, class XB>
 __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, int nchunks, f32x4 (&acc)[2][NT],
                                                float* lds) {
     using T = GT<NT>;
@@ -114,34 +114,72 @@ __device__ __forceinline__ void gemm_mainloop2(LA& la, XA& xa, LB& lb, XB& xb, i
     float* As1 = lds + T::A_FLOATS;
     float* Bs0 = lds + 2 * T::A_FLOATS;
     float* Bs1 = Bs0 + T::B_FLOATS;
-
-    if (nchunks > 0) {
-        TFNAS_GLOAD(0);
-        TFNAS_SSTORE(0, As0, Bs0);
+#define TFNAS_MFMAS(As, Bs)                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                      \
+        const int k = ks * 4 + lk;                                                          \
+        const float a0 = (As)[k * T::LDA + wrow + lr];                                      \
+        const float a1 = (As)[k * T::LDA + wrow + 16 + lr];                                 \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                    \
+            const float b = (Bs)[k * T::LDB + 16 * j + lr];                                 \
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);    \
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);    \
+        }                                                                                   \
     }
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const float* As = (c & 1) ? As1 : As0;
-        const float* Bs = (c & 1) ? Bs1 : Bs0;
-        const bool more = (c + 1 < nchunks);
-        if (more) TFNAS_GLOAD(c + 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int k = ks * 4 + lk;
-            const float a0 = As[k * T::LDA + wrow + lr];
-            const float a1 = As[k * T::LDA + wrow + 16 + lr];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float b = Bs[k * T::LDB + 16 * j + lr];
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
-            }
+
+    if (PF2) {
+        // prefetch distance 2 for launches that leave a CU with one or two workgroups (SE excite GEMMs: 1-20 workgroups;
+        // weight-gradient GEMMs of the 14x14 / 7x7 cells: 1.3 per CU): the loads of chunk c+2 are issued before the MFMAs
+        // of chunk c and consumed after those of chunk c+1.  Two raw register sets, alternating statically (loop unrolled
+        // by two).  (In the row-tiled GEMMs, which run at 3-4 workgroups per CU under launch bounds, the same scheme
+        // was slower: gemm_mainloop_adirect.)
+        RA qa[2];
+        RB qb[T::B_ITERS];
+#define TFNAS_SWAP_SETS()                                                                   \
+    {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) { const RA t_ = ra[i]; ra[i] = qa[i]; qa[i] = t_; }          \
+        _Pragma("unroll") for (int i = 0; i < T::B_ITERS; ++i) { const RB t_ = rb[i]; rb[i] = qb[i]; qb[i] = t_; } \
+    }
+        // ra/rb always name the set the macros work on; the two physical sets trade places by register renaming only
+        // (the loop body is unrolled by two, so the swaps are compile-time)
+        if (nchunks > 0) {
+            TFNAS_GLOAD(0);
+            TFNAS_SSTORE(0, As0, Bs0);
         }
-        if (more) {
-            if (c & 1) { TFNAS_SSTORE(c + 1, As0, Bs0); } else { TFNAS_SSTORE(c + 1, As1, Bs1); }
+        if (nchunks > 1) TFNAS_GLOAD(1);          // set X holds chunk 1
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            TFNAS_SWAP_SETS();                        // ra = set Y (free), qa = set X (chunk c+1)
+            if (c + 2 < nchunks) TFNAS_GLOAD(c + 2);  // set Y <- chunk c+2
+            TFNAS_MFMAS(As0, Bs0);
+            TFNAS_SWAP_SETS();                        // ra = set X (chunk c+1), qa = set Y (chunk c+2)
+            if (c + 1 < nchunks) TFNAS_SSTORE(c + 1, As1, Bs1);
+            __syncthreads();
+            if (c + 1 >= nchunks) break;
+            if (c + 3 < nchunks) TFNAS_GLOAD(c + 3);  // set X <- chunk c+3
+            TFNAS_MFMAS(As1, Bs1);
+            TFNAS_SWAP_SETS();                        // ra = set Y (chunk c+2), qa = set X (chunk c+3)
+            if (c + 2 < nchunks) TFNAS_SSTORE(c + 2, As0, Bs0);
+            TFNAS_SWAP_SETS();                        // ra = set X (chunk c+3) -- what the next iteration expects in "X"
+            __syncthreads();
+        }
+#undef TFNAS_SWAP_SETS
+    } else {
+        if (nchunks > 0) {
+            TFNAS_GLOAD(0);
+            TFNAS_SSTORE(0, As0, Bs0);
         }
         __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = (c + 1 < nchunks);
+            if (more) TFNAS_GLOAD(c + 1);
+            if (c & 1) { TFNAS_MFMAS(As1, Bs1); } else { TFNAS_MFMAS(As0, Bs0); }
+            if (more) {
+                if (c & 1) { TFNAS_SSTORE(c + 1, As0, Bs0); } else { TFNAS_SSTORE(c + 1, As1, Bs1); }
+            }
+            __syncthreads();
+        }
     }
+#undef TFNAS_MFMAS
 #undef TFNAS_GLOAD
 #undef TFNAS_SSTORE
 #undef TFNAS_A_IDX

@@ -30,6 +30,9 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
 
 // resident workgroups per CU the row-tiled GEMM kernels are compiled for (register cap 512 / n per lane): 5-/7-tile and
 // narrower variants
+#ifndef TFNAS_WGRAD_PF2
+#define TFNAS_WGRAD_PF2 false  /* prefetch distance 2 in the weight-gradient GEMMs (A/B) */
+#endif
 #ifndef TFNAS_LB_BIG
 #define TFNAS_LB_BIG 3
 #endif
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
         return (bok[i] && r0 + c * 16 + kl < r1) ? v : zero4();
     };
     WGT(1)
-    gemm_mainloop2<NT, false, false, false>(la, xa, lb, xb, nchunks, acc, lds);
+    gemm_mainloop2<NT, false, false, false, TFNAS_WGRAD_PF2>(la, xa, lb, xb, nchunks, acc, lds);
     WGT(2)
     // The gradient is [oc][mc] (mid channel fastest) and a lane's accumulator quad is 4 consecutive mid channels of one
     // output channel: one 16-byte store per quad (the four lane groups of an output channel then cover 64 contiguous
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
         if (STEM) return r;
         return (bok[i] && r0 + c * 16 + kl < r1) ? r : zero4();
     };
-    gemm_mainloop2<NT, false, false, false>(la, xa, lb, xb, nchunks, acc, lds);
+    gemm_mainloop2<NT, false, false, false, TFNAS_WGRAD_PF2>(la, xa, lb, xb, nchunks, acc, lds);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

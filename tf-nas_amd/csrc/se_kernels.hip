@@ -14,6 +14,10 @@
 #include "kernels.h"
 #include "prof.h"
 
+#ifndef TFNAS_SE_PF2
+#define TFNAS_SE_PF2 false     /* prefetch distance 2 in the K loop (gemm_core.h); measured: no gain (A/B switch) */
+#endif
+
 struct SeArgs {
     const float* pooled;   // [N][M]
     const float* gate;     // [N][M]
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
             return (n0 + nn < se && (cbase + c) * 16 + kl < mc) ? v : zero4();
         };
         const int tot = (mcp + 15) >> 4;
-        gemm_mainloop2<NT, true, true>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
+        gemm_mainloop2<NT, true, true, true, TFNAS_SE_PF2>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 1) {
         if (r0 >= N || n0 >= mcp) return;
         auto la = [&](int c, int, int row, int kl) -> f32x4 {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
         auto xb = [&](f32x4 v, int c, int, int nn, int kl) -> f32x4 {
             return (n0 + nn < mc && c * 16 + kl < se) ? v : zero4();
         };
-        gemm_mainloop2<NT, true, true>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
+        gemm_mainloop2<NT, true, true, true, TFNAS_SE_PF2>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
     } else if (MODE == 2) {
         if (r0 >= N || n0 >= se) return;
         auto la = [&](int c, int, int row, int kl) -> Pair {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
             return ((cbase + c) * 16 + kl < mc && n0 + nn < se) ? v : zero4();
         };
         const int tot = (mcp + 15) >> 4;
-        gemm_mainloop2<NT, true, false>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
+        gemm_mainloop2<NT, true, false, true, TFNAS_SE_PF2>(la, xa, lb, xb, split ? max(0, min(cps, tot - cbase)) : tot, acc, lds);
     } else if (MODE == 3) {
         if (r0 >= N || n0 >= mcp) return;
         auto la = [&](int c, int, int row, int kl) -> f32x4 {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
             if (!mc_al) return v;
             return (c * 16 + kl < se && n0 + nn < mc) ? v : zero4();
         };
-        gemm_mainloop2<NT, true, false>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
+        gemm_mainloop2<NT, true, false, true, TFNAS_SE_PF2>(la, xa, lb, xb, (se + 15) >> 4, acc, lds);
     } else {   // MODE 4 / 5: rows = mid channels, cols = se, K = batch
         if (r0 >= mcp || n0 >= se) return;
         auto la = [&](int c, int, int kl, int m) -> Pair {
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void k_se_gemm(TfnasCellDesc d, SeArgs a) {
             const f32x4 w = MODE == 4 ? act_f4<ACT>(v) : v;
             return (c * 16 + kl < N && n0 + nn < se) ? w : zero4();
         };
-        gemm_mainloop2<NT, false, false>(la, xa, lb, xb, (N + 15) >> 4, acc, lds);
+        gemm_mainloop2<NT, false, false, true, TFNAS_SE_PF2>(la, xa, lb, xb, (N + 15) >> 4, acc, lds);
     }
     (void)id;
 

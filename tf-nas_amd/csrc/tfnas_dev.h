@@ -90,14 +90,31 @@ __device__ __forceinline__ unsigned bf16_rne(float f) {
     const unsigned u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;          // (NaN payloads are not preserved; none occur here)
 }
+// gfx950 has the packed conversion in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): 2 instructions per quad where the
+// integer sequence above took ~20 -- the stores of the bf16 mode sit in VALU-bound kernels
+typedef float tf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tf_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 bf16x4_narrow(f32x4 v) {
+#ifdef TFNAS_BF16_SW
+    uint2 r0;
+    r0.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+    r0.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+    return r0;
+#endif
+    const tf_f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    const tf_bf16x2 a = __builtin_convertvector(lo, tf_bf16x2), b = __builtin_convertvector(hi, tf_bf16x2);
     uint2 r;
-    r.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
-    r.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+    r.x = *reinterpret_cast<const unsigned*>(&a);
+    r.y = *reinterpret_cast<const unsigned*>(&b);
     return r;
 }
-#ifdef TFNAS_NO_BF16                 /* A/B builds: compile the bf16 branches out */
+#if defined(TFNAS_NO_BF16)           /* the product library: bf16 branches compiled out */
 #define TFNAS_STOR(s) 0
+#elif defined(TFNAS_ONLY_BF16)       /* the bf16 library: fp32-storage branches compiled out (its plan accepts stor = 1 only).
+                                        As wave-uniform RUNTIME branches around every load / store of the stream tensors they
+                                        broke the kernels' load pipelines into dozens of basic blocks: 1.2-1.75x slower per
+                                        kernel than the fp32 build although the bytes halve */
+#define TFNAS_STOR(s) 1
 #else
 #define TFNAS_STOR(s) (s)
 #endif

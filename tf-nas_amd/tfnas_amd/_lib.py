@@ -111,8 +111,9 @@ _libs = {}
 
 
 def lib(bf16=False):
-    """Load (once) and return the shared library; raises RuntimeError when it is absent.  ``bf16=True``: the build that also
-    accepts TfnasCellDesc.stor = 1."""
+    """Load (once) and return the shared library; raises RuntimeError when it is absent.  ``bf16=True``: the build for
+    TfnasCellDesc.stor = 1 (bf16 storage of the stream tensors; MixedOP cells only -- each library is compiled for ONE storage
+    mode, stems / head / fp32 cells always go through the default one)."""
     l = _libs.get(bool(bf16))
     if l is None:
         path = LIB_PATH_BF16 if bf16 else LIB_PATH
