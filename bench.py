@@ -275,6 +275,10 @@ def run_gpu(args):
         dt = float(t)
     dom = collect()[dominant]
     lib.tfnas_prof_enable(0)
+    # a throughput number from a diverged run is worthless (NaN arithmetic runs at full speed): every parameter must be finite
+    bad = [n for n, p in model.named_parameters() if not bool(torch.isfinite(p).all())]
+    if bad:
+        raise RuntimeError('bench: non-finite parameters after the timed region: %s ...' % bad[:3])
 
     # ---- after the timed region: GPU time of the w-step and the alpha-step (HIP events on the launch stream; the
     # w-step's side streams fork from and join it) over a few more pairs

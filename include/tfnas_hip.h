@@ -113,8 +113,11 @@ typedef struct TfnasCellWs {
     uint64_t off_dgate, off_dpooled, off_dgl, off_dhpre, off_cb1;
     uint64_t red;      /* doubles red3[G*oc][2] | resdot[oc] | red2[M][2] | red1[M][2]      */
     uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = per-channel <dout, x> of residual cells */
-    uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd); reductions are done by a
-                          second tiny kernel instead of device-scope atomics -> deterministic results.
+    uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd), summed in a fixed order by the
+                          producer's last workgroup or a second tiny kernel -- no floating-point atomics, deterministic
+                          results.  A multiple of tfnas_sizeof(7) floats; the LAST tfnas_sizeof(8) 4-byte words of every
+                          tfnas_sizeof(7)-float piece are ticket counters: they must be ZERO when the buffer is first
+                          passed to the library (zero them once after allocating; every call leaves them zero).
                           Doubled when d.need_wgrad is set: tfnas_mixedop_bwd runs the weight-gradient kernels on
                           a library-owned side stream (forked from / joined to `stream` inside the call) and gives
                           them the second half.                                                              */
@@ -133,7 +136,8 @@ int tfnas_has_bf16_storage(void);
 int tfnas_shutdown(void);
 
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs,
- * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs, 6 TfnasBnAffine. */
+ * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs, 6 TfnasBnAffine;  7 = floats of one `part` scratch piece, 8 = ticket-counter
+ * words at the end of each piece (TfnasCellWs.part). */
 uint64_t tfnas_sizeof(int which);
 
 /* Fill the [plan] fields of a descriptor from its [in] fields.  Returns TFNAS_E* on bad geometry. */
@@ -294,7 +298,8 @@ typedef struct TfnasPathDesc {
     TfnasCellDesc cell[TFNAS_MAX_CELLS];   /* [in] fields + weight / gradient pointers bound; N, H, W chained by plan */
 } TfnasPathDesc;
 
-/* Arena requirement of a planned path, in floats (the arena must be 256-byte aligned). */
+/* Arena requirement of a planned path, in floats (the arena must be 256-byte aligned and ZERO-FILLED once after allocation:
+ * its `part` pieces hold ticket counters, see TfnasCellWs.part; the library keeps them zero afterwards). */
 typedef struct TfnasPathWs {
     uint64_t saved;         /* forward results kept for backward (E, D, Pr, small tensors, statistics, cell / stage outputs) */
     uint64_t scratch;       /* forward + backward scratch (partials, dZ, dEh, gradient ring)                  */

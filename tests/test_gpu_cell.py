@@ -134,3 +134,15 @@ def test_backward_without_input_grad_only_produces_dwmix():
     out_m = MixedOpFn.apply(plan, xm, w_m, *ps)
     (out_m * r.cuda()).sum().backward()
     assert torch.allclose(w_m.grad.cpu(), w_o.grad, atol=1e-3 + 1e-3 * float(w_o.grad.abs().max()))
+
+
+def test_last_workgroup_reductions_switch():
+    """TFNAS_TAIL=1 (csrc/tail_reduce.h: statistics summed by the producer's last workgroup, off by default) must give the
+    same cell results; the switch is read once per process, hence the subprocess."""
+    import os, subprocess, sys
+    env = dict(os.environ, TFNAS_TAIL='1')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_cell.py'), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_soft_mode_all_stages and (tiny or wide_tile_edge or real_s2b2_28 or real_s3b1_28)'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

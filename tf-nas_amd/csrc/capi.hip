@@ -114,6 +114,8 @@ extern "C" uint64_t tfnas_sizeof(int which) {
         case 4: return sizeof(TfnasPathDesc);
         case 5: return sizeof(TfnasPathWs);
         case 6: return sizeof(TfnasBnAffine);
+        case 7: return TFNAS_PART_ALLOC;      // floats of one `part` scratch region ...
+        case 8: return TFNAS_TAIL_SLOTS;      // ... whose last this-many 4-byte words are ticket counters (zero on first use)
         default: return 0;
     }
 }
@@ -209,7 +211,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_red2 = 2 * G * oc + oc;
     ws->off_red1 = ws->off_red2 + 2 * M;
     ws->red = ws->off_red1 + 2 * M;
-    ws->part = (d->need_wgrad ? 2 : 1) * (uint64_t)TFNAS_PART_FLOATS;   // second half: weight-gradient side stream
+    ws->part = (d->need_wgrad ? 2 : 1) * (uint64_t)TFNAS_PART_ALLOC;   // second half: weight-gradient side stream
     ws->dx = P * d->ic;
     {
         const int ns = d->mode == TFNAS_MODE_STEM ? 1 : expand_dgrad_splits(*d);
@@ -408,7 +410,7 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
         so.side = sc->side;
         for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
     }
-    CellBwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_FLOATS,
+    CellBwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_ALLOC,
                      dx, dxp, dwmix, nullptr, nullptr};
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
     return guard.join();
@@ -448,7 +450,7 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
         so.side = sc->side;
         for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
     }
-    CellBwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_FLOATS,
+    CellBwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_ALLOC,
                      dx, dxp, nullptr, nullptr, nullptr};
     b.bn = bn;
     b.drop_scale = drop_scale;

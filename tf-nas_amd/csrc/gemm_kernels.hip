@@ -65,7 +65,8 @@ struct RawWS { f32x4 w; float s; };      // a weight quad and its row scale
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT, bool STEM>
 __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
-                                                    float* __restrict__ E, float* __restrict__ part) {
+                                                    float* __restrict__ E, float* __restrict__ part,
+                                                    unsigned* __restrict__ tail_cnt, double* __restrict__ stats1) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     int ty = blockIdx.y, g = 0;
@@ -122,7 +123,13 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
         });
         acc_colstats<NT>(acc, cs, cq);
     }
-    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp);
+    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp, tail_cnt != nullptr);
+    if (tail_cnt && tail_ticket(tail_cnt + blockIdx.y, gridDim.x, lds)) {
+        // BN1 statistics of this column tile, summed by the workgroup that finished last
+        const int nc = 2 * (min(mcp, n0 + T::BN) - n0);
+        tail_reduce_cols(part, TFNAS_PART_FLOATS, 2 * (size_t)M, gridDim.x, 2 * (off + n0), nc, lds,
+                         [&](int c, double t0, double t1) { stats1[c] = t0; stats1[c + 1] = t1; });
+    }
 }
 
 // ============================================================================ project forward
@@ -134,7 +141,8 @@ template <int NT, int ACT>
 __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
-                                                     float* __restrict__ part, int nsplit, float* __restrict__ prp) {
+                                                     float* __restrict__ part, int nsplit, float* __restrict__ prp,
+                                                     unsigned* __restrict__ tail_cnt, double* __restrict__ stats3) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // nsplit > 1 (under-filled launches: few row tiles, long K): K-split ks of group g adds chunks [cb, ce); split 0
@@ -221,8 +229,16 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
         });
         acc_colstats<NT>(acc, cs, cq);
     }
-    if (nsplit == 1)
-        flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
+    if (nsplit == 1) {
+        flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc,
+                           tail_cnt != nullptr);
+        if (tail_cnt && tail_ticket(tail_cnt + blockIdx.y + gridDim.y * blockIdx.z, gridDim.x, lds)) {
+            // BN3 statistics of this (group, column tile), summed by the workgroup that finished last
+            const int nc = 2 * (min(oc, n0 + T::BN) - n0);
+            tail_reduce_cols(part, TFNAS_PART_FLOATS, 2 * (size_t)d.G * oc, gridDim.x, 2 * (g * oc + n0), nc, lds,
+                             [&](int c, double t0, double t1) { stats3[c] = t0; stats3[c + 1] = t1; });
+        }
+    }
 }
 
 // Pr[g][p][:] += sum_z prp[z][g][p][:] and the per-workgroup partial (sum, sumsq) of the finished Pr per (g, column):
@@ -845,7 +861,9 @@ static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channe
 // kernels with a statistics epilogue: at most 1024 partial rows (k_reduce_rows folds 512 per round trip) and they must fit
 static size_t stats_row_cap(size_t row_floats) {
     const size_t fit = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
-    return fit < 1024 ? fit : 1024;
+    // "last workgroup reduces" (tail_reduce_cols): one workgroup sums a column tile over all rows -- keep that tail short
+    static const size_t lim = getenv("TFNAS_TAIL_ROWS") ? (size_t)atoi(getenv("TFNAS_TAIL_ROWS")) : 1024;
+    return fit < lim ? fit : lim;
 }
 
 // Number of persistent row blocks (grid.x) of a row-tiled GEMM launch.  The launch runs gx * other workgroups on
@@ -914,17 +932,19 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt)), tiles);
+    unsigned* tcnt = (tail_enabled() && tiles <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
     if (d.mode == TFNAS_MODE_STEM) {
-        if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true>), grid, dim3(256), 0, s, d, x, E, part);
-        else hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part);
+        if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
+        else hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
     } else {
         switch (nt) {
-            case 5: hipLaunchKernelGGL((k_expand_fwd<5, false>), grid, dim3(256), 0, s, d, x, E, part); break;
-            case 7: hipLaunchKernelGGL((k_expand_fwd<7, false>), grid, dim3(256), 0, s, d, x, E, part); break;
-            default: hipLaunchKernelGGL((k_expand_fwd<4, false>), grid, dim3(256), 0, s, d, x, E, part); break;
+            case 5: hipLaunchKernelGGL((k_expand_fwd<5, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+            case 7: hipLaunchKernelGGL((k_expand_fwd<7, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+            default: hipLaunchKernelGGL((k_expand_fwd<4, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
         }
     }
     _prof.stop();
+    if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
@@ -955,7 +975,8 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         dim3 grid(nrt, tiles, d.G * nsplit);
         DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
             const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-            hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp);
+            hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp,
+                               (unsigned*)nullptr, (double*)nullptr);
         }))
         int gx2 = cdiv(Po, 64);
         if (gx2 > 256) gx2 = 256;
@@ -966,12 +987,14 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         return launch_reduce_rows(part2, gx2, ncols2, (size_t)ncols2, stats3, nullptr, s);
     }
     dim3 grid(row_blocks(Po, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt)), tiles, d.G);
+    unsigned* tcnt = (tail_enabled() && tiles * d.G <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, 1,
-                           (float*)nullptr);
+                           (float*)nullptr, tcnt, stats3);
     }))
     _prof.stop();
+    if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
 }
 

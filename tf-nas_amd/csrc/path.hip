@@ -110,8 +110,16 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
             if (d.ic != d.oc || d.stride != 1) return TFNAS_EINVAL;     // depth outputs of a stage share one shape
         }
     }
-    // ---- arena layout: saved region
+    // ---- arena layout.  First, at FIXED offsets (the same for every plan of this context, whatever widths it samples): the
+    // `part` scratch pieces -- their tails hold the ticket counters of the "last workgroup reduces" epilogues, which must
+    // stay zero between launches (kernels.h), so they may never land on memory another plan used for something else.
     uint64_t off = 0;
+    for (int k = 0; k < NSET; ++k) {
+        ScratchSet& s = c.set[k];
+        s.part = off; off += up(TFNAS_PART_ALLOC);
+        s.part_w = off; off += up(TFNAS_PART_ALLOC);
+    }
+    // ---- saved region
     for (int i = 0; i < pd.ncell; ++i) {
         const TfnasCellWs& w = c.cws[i];
         const bool efree = (pd.efree_mask_lo >> i) & 1;
@@ -157,8 +165,6 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         s.dEh = off; off += up(mdEh);
         s.bsmall = off; off += up(mbs);
         s.red = off; off += up(2 * mred);
-        s.part = off; off += up(TFNAS_PART_FLOATS);
-        s.part_w = off; off += up(TFNAS_PART_FLOATS);
     }
     for (int k = 0; k < NRING; ++k) { c.ring[k] = off; off += up(mring); }
     c.dxp = off; off += up(mdxp);

@@ -144,7 +144,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
     fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
     stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
-    part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+    part = _part(ws.part, dev)
     out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
     if wmix is not None:
         wmix = wmix.contiguous()
@@ -172,7 +172,7 @@ def _cell_backward(ctx, dout, want_dx):
     bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
     # with weight gradients the library wants twice the scratch (second half: its weight-gradient side stream)
-    part = torch.empty(ws.part * (2 if need_w else 1), device=dev, dtype=torch.float32)
+    part = _part(ws.part * (2 if need_w else 1), dev)
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
@@ -241,7 +241,7 @@ class HeadFn(torch.autograd.Function):
         dev = x.device
         E = torch.empty(ws.E, device=dev, dtype=torch.float32)
         stats = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        part = _part(ws.part, dev)
         pooled = torch.empty((N, d.g[0].mc), device=dev, dtype=torch.float32)
         _same_device(dev, [w], 'the feature_mix weight')
         with _on(dev):
@@ -263,7 +263,7 @@ class HeadFn(torch.autograd.Function):
         dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
         cb1 = torch.empty(4 * d.M, device=dev, dtype=torch.float32)
         red = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        part = _part(ws.part, dev)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
         dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32)
         with _on(dev):
@@ -391,6 +391,16 @@ class SinkFn(torch.autograd.Function):
 # ======================================================================================================================
 # Derived-network ("retrain") path: blocks with AFFINE BatchNorm + running statistics + drop-connect
 # (models/model_eval.py, models/layers.py with affine=True, tools/utils.py:77-86) on the same kernels -- tfnas_mbconv_fwd/bwd.
+def _part(floats, dev):
+    """A `part` scratch buffer with its ticket counters zeroed (include/tfnas_hip.h, TfnasCellWs.part)."""
+    l = _lib.lib()
+    piece, slots = int(l.tfnas_sizeof(7)), int(l.tfnas_sizeof(8))
+    floats = -(-int(floats) // piece) * piece
+    buf = torch.empty(floats, device=dev, dtype=torch.float32)
+    buf.view(-1, piece)[:, piece - slots:].zero_()
+    return buf
+
+
 def _bn_struct(bns, training, grads=None):
     """TfnasBnAffine for up to three nn.BatchNorm2d modules (None entries: site without affine)."""
     a = _lib.TfnasBnAffine()
@@ -432,7 +442,7 @@ class MBConvAffineFn(torch.autograd.Function):
         Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
         fsmall = torch.empty(ws.fsmall, device=dev, dtype=torch.float32)
         stats = torch.empty(ws.stats, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        part = _part(ws.part, dev)
         out = torch.empty((N, d.Ho, d.Wo, plan.oc), device=dev, dtype=torch.float32)
         bn = _bn_struct(bns, training)
         ds = None if drop_scale is None else drop_scale.contiguous().float()
@@ -464,7 +474,7 @@ class MBConvAffineFn(torch.autograd.Function):
         dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
         bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
         red = torch.empty(ws.red, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part * 2, device=dev, dtype=torch.float32)
+        part = _part(ws.part * 2, dev)
         dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
         dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
         dout_s = torch.empty_like(douth) if ds is not None else None
@@ -490,7 +500,7 @@ class HeadAffineFn(torch.autograd.Function):
         dev = x.device
         E = torch.empty(ws.E, device=dev, dtype=torch.float32)
         stats = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        part = _part(ws.part, dev)
         pooled = torch.empty((N, d.g[0].mc), device=dev, dtype=torch.float32)
         bn = _bn_struct([bn_mod], training)
         with _on(dev):
@@ -515,7 +525,7 @@ class HeadAffineFn(torch.autograd.Function):
         dEh = torch.empty(ws.dEh, device=dev, dtype=torch.float32)
         cb1 = torch.empty(4 * d.M, device=dev, dtype=torch.float32)
         red = torch.empty(2 * d.M, device=dev, dtype=torch.float64)
-        part = torch.empty(ws.part, device=dev, dtype=torch.float32)
+        part = _part(ws.part, dev)
         dx = torch.empty((N, H, W, plan.ic), device=dev, dtype=torch.float32)
         dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32)
         bn = _bn_struct([ctx.bn_mod], ctx.training, gbn)

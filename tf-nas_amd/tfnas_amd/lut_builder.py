@@ -35,7 +35,7 @@ class _BlockTimer:
     def _buf(self, name, n, dtype=torch.float32):
         t = self.bufs.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
-            t = self.bufs[name] = torch.empty(int(n * 1.25) + 64, device=self.dev, dtype=dtype)
+            t = self.bufs[name] = torch.zeros(int(n * 1.25) + 64, device=self.dev, dtype=dtype)   # zero: `part` ticket counters
         return t
 
     def measure(self, ic, mc, se, oc, k, stride, act, size, batch=32, warmup=3, iters=10, reps=3):

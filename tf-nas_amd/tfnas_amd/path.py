@@ -237,7 +237,7 @@ class PathRunner:
         if s.arena is not None:
             torch.cuda.synchronize(self.device)             # (pending kernels may still use the old arena)
         s.arena = None
-        s.arena = torch.empty(int(need * 1.02) + 1024, device=self.device, dtype=torch.float32)
+        s.arena = torch.zeros(int(need * 1.02) + 1024, device=self.device, dtype=torch.float32)   # zero: ticket counters (tfnas_hip.h)
 
     def _sampled_need(self, name, wide, x0h, need_wgrad, need_dx0):
         tmp = '_size_probe'
