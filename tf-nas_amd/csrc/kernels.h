@@ -87,8 +87,7 @@ struct DwTail {
 // summed by the producer's last workgroup (tail_reduce.h) instead of a separate k_reduce_rows launch.  OFF by default --
 // measured: 4 of the 6-9 reduce launches per cell pass disappear, but the ticket (wait for the write-through stores + one
 // agent-scope atomic, paid by every workgroup) plus the winner's coherent read-back cost the producers what the tiny
-// launches cost (per-cell kernel time unchanged within 1 %, pair 74.6 -> 75.5 ms).  An upper bound on what free reductions
-// would give was seen by accident (counters on stale memory: no workgroup ever won, nothing was reduced): 70.8 ms.
+// launches cost (per-cell kernel time unchanged within 1 %, pair 74.6 -> 75.5 ms).
 static inline bool tail_enabled() {
     static const int on = [] { const char* e = getenv("TFNAS_TAIL"); return (e && e[0] == '1') ? 1 : 0; }();
     return on == 1;
