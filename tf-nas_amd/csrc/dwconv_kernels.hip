@@ -392,7 +392,12 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
 
         for (int item = tid; item < nstrips * CQ; item += 256) {
             const int cq = item & (CQ - 1), st = item >> gm.cq_shift;
-            const int ih = st / nsw, iw0 = (st - ih * nsw) * 4;
+            // stride 2: which taps reach an input row depends on the row's parity, and a wave holds the strips of 2-4
+            // consecutive rows -- in natural order half of its lanes sat out every ky iteration of the tap loop.  Rows are
+            // therefore dealt even-first (0, 2, 4, .., 1, 3, ..): the rows of a wave share their parity.
+            const int ihp = st / nsw, iw0 = (st - ihp * nsw) * 4;
+            const int half = (TIH + 1) >> 1;
+            const int ih = (S == 2) ? (ihp < half ? 2 * ihp : 2 * (ihp - half) + 1) : ihp;
             const int hi = hi0 + ih;
             f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
             // issue the epilogue's E loads now so that their latency hides under the tap loop
