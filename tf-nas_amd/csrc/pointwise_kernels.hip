@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
     if (!chunk_locate(d, blockIdx.y, 64, true, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x;
-    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    // threads = (channel quad) x (row lane): a chunk narrower than 64 channels (the 32-channel stem, the last chunk of a
+    // 96- / 144- / 240-wide group) gives its spare quad slots to more row lanes instead of leaving half the block idle
+    const int nq = (min(64, mcp - c0) + 3) >> 2, cqs = nq <= 4 ? 2 : (nq <= 8 ? 3 : 4), CQN = 1 << cqs, RLN = 256 >> cqs;
+    const int tid = threadIdx.x, cq = tid & (CQN - 1), rl = tid >> cqs;
     const int ch = c0 + 4 * cq;
     const bool active = ch < mcp;
     float2 c2[4];
@@ -62,18 +65,18 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
                                         : make_float2(0.f, 0.f);
     f32x4 acc = zero4();
     if (active) {
-        for (int hw = rl; hw < HW; hw += 64) {        // 4 independent rows in flight per thread
+        for (int hw = rl; hw < HW; hw += 4 * RLN) {        // 4 independent rows in flight per thread
             f32x4 v[4], z[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int h = hw + 16 * u;
+                const int h = hw + RLN * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
                 v[u] = ldS4_nt(D, a, d.stor);
                 z[u] = (MODE == 1) ? ldS4_nt(dZ, a, d.stor) : zero4();
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (hw + 16 * u < HW) {
+                if (hw + RLN * u < HW) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[u][j] = act_f<ACT>((v[u][j] - c2[j].x) * c2[j].y);
                     acc += (MODE == 1) ? v[u] * z[u] : v[u];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
             }
         }
     }
-    acc = reduce_rows(acc, buf, rl, cq, 16, 16, active);
+    acc = reduce_rows(acc, buf, rl, cq, RLN, CQN, active);
     if (active && rl == 0) {
         if (MODE == 0) acc *= splat4(1.f / (float)HW);
         st4(outp + (size_t)n * M + off + ch, acc);
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0;
     const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x;
-    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int nq = (min(64, mcp - c0) + 3) >> 2, cqs = nq <= 4 ? 2 : (nq <= 8 ? 3 : 4), CQN = 1 << cqs, RLN = 256 >> cqs;
+    const int tid = threadIdx.x, cq = tid & (CQN - 1), rl = tid >> cqs;       // (see k_se_pool)
     const int ch = c0 + 4 * cq;
     const bool active = ch < mcp;
     float2 c2[4];
@@ -223,18 +227,18 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
                                         : make_float2(0.f, 0.f);
     f32x4 g0 = zero4(), a1 = zero4(), b1 = zero4(), a2 = zero4(), b2 = zero4();
     if (active) {
-        for (int hw = rl; hw < HW; hw += 64) {        // 4 independent rows in flight per thread
+        for (int hw = rl; hw < HW; hw += 4 * RLN) {        // 4 independent rows in flight per thread
             f32x4 v[4], z[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int h = hw + 16 * u;
+                const int h = hw + RLN * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
                 v[u] = ldS4_nt(D, a, d.stor);
                 z[u] = ldS4_nt(dZ, a, d.stor);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (hw + 16 * u < HW) {
+                if (hw + RLN * u < HW) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float dh = (v[u][j] - c2[j].x) * c2[j].y;
@@ -252,16 +256,16 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
         }
     }
     const size_t NM = (size_t)d.N * M, o = (size_t)n * M + off + ch;
-    a1 = reduce_rows(a1, buf, rl, cq, 16, 16, active);
+    a1 = reduce_rows(a1, buf, rl, cq, RLN, CQN, active);
     if (active && rl == 0) st4(pp + o, a1);
-    b1 = reduce_rows(b1, buf, rl, cq, 16, 16, active);
+    b1 = reduce_rows(b1, buf, rl, cq, RLN, CQN, active);
     if (active && rl == 0) st4(pp + NM + o, b1);
     if (has_se) {
-        a2 = reduce_rows(a2, buf, rl, cq, 16, 16, active);
+        a2 = reduce_rows(a2, buf, rl, cq, RLN, CQN, active);
         if (active && rl == 0) st4(pp + 2 * NM + o, a2);
-        b2 = reduce_rows(b2, buf, rl, cq, 16, 16, active);
+        b2 = reduce_rows(b2, buf, rl, cq, RLN, CQN, active);
         if (active && rl == 0) st4(pp + 3 * NM + o, b2);
-        g0 = reduce_rows(g0, buf, rl, cq, 16, 16, active);
+        g0 = reduce_rows(g0, buf, rl, cq, RLN, CQN, active);
         if (active && rl == 0) st4(dgate + o, g0);
     }
 }
