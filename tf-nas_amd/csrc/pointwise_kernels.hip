@@ -41,6 +41,10 @@ static int chunk_count(const TfnasCellDesc& d, int CH, bool se_only) {
     return t;
 }
 // ============================================================================ SE squeeze (global average pool)
+#ifndef TFNAS_POOL_ROWS
+#define TFNAS_POOL_ROWS 4
+#endif
+constexpr int PU = TFNAS_POOL_ROWS;      // pixel rows in flight per thread of the pooling kernels
 // MODE 0: pooled[n][c] = mean_hw act(BN2(D))            (forward)
 // MODE 1: dgate [n][c] = sum_hw  dZ * act(BN2(D))       (backward of the gate multiply)
 template <int ACT, int MODE>
@@ -65,17 +69,17 @@ __global__ __launch_bounds__(256) void k_se_pool(TfnasCellDesc d, const float* _
                                         : make_float2(0.f, 0.f);
     f32x4 acc = zero4();
     if (active) {
-        for (int hw = rl; hw < HW; hw += 4 * RLN) {        // 4 independent rows in flight per thread
-            f32x4 v[4], z[4];
+        for (int hw = rl; hw < HW; hw += PU * RLN) {        // PU independent rows in flight per thread
+            f32x4 v[PU], z[PU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 const int h = hw + RLN * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
                 v[u] = ldS4_nt(D, a, d.stor);
                 z[u] = (MODE == 1) ? ldS4_nt(dZ, a, d.stor) : zero4();
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 if (hw + RLN * u < HW) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[u][j] = act_f<ACT>((v[u][j] - c2[j].x) * c2[j].y);
@@ -227,17 +231,17 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
                                         : make_float2(0.f, 0.f);
     f32x4 g0 = zero4(), a1 = zero4(), b1 = zero4(), a2 = zero4(), b2 = zero4();
     if (active) {
-        for (int hw = rl; hw < HW; hw += 4 * RLN) {        // 4 independent rows in flight per thread
-            f32x4 v[4], z[4];
+        for (int hw = rl; hw < HW; hw += PU * RLN) {        // PU independent rows in flight per thread
+            f32x4 v[PU], z[PU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 const int h = hw + RLN * u;
                 const size_t a = ((size_t)n * HW + (h < HW ? h : 0)) * M + off + ch;
                 v[u] = ldS4_nt(D, a, d.stor);
                 z[u] = ldS4_nt(dZ, a, d.stor);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 if (hw + RLN * u < HW) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
