@@ -26,7 +26,10 @@ struct ScratchSet {
 
 // The weight-gradient kernels of a cell run on the side stream and may finish up to LAG cells after the data-gradient chain
 // has moved on: LAG + 1 scratch sets and LAG + 2 gradient-ring slots keep everything they read alive that long.
-constexpr int LAG = 2;
+#ifndef TFNAS_LAG
+#define TFNAS_LAG 2
+#endif
+constexpr int LAG = TFNAS_LAG;
 constexpr int NSET = LAG + 1, NRING = LAG + 2;
 
 struct PathCtx {
