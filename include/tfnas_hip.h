@@ -65,7 +65,7 @@ extern "C" {
 typedef struct TfnasGroup {
     int32_t mc;       /* mid channels (any integer > 0, e.g. 53)            [in]  */
     int32_t k;        /* depthwise kernel size: 3 or 5                      [in]  */
-    int32_t se;       /* squeeze-excite width, 0 = no SE                    [in]  */
+    int32_t se;       /* squeeze-excite width (a multiple of 4), 0 = no SE   [in]  */
     int32_t mcp;      /* mc rounded up to a multiple of 4                   [plan] */
     int32_t off;      /* first column of this group in the [.][M] tensors (multiple of 32) [plan] */
     int32_t se_off;   /* first column in the [N][SE] hidden tensors         [plan] */

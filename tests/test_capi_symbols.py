@@ -75,6 +75,7 @@ def test_error_codes(lib):
     assert lib.tfnas_cell_plan(C.byref(_desc(ic=22))) == -1          # ic % 4
     assert lib.tfnas_cell_plan(C.byref(_desc(stride=3))) == -1
     assert lib.tfnas_cell_plan(C.byref(_desc(ks=(3, 7)))) == -1
+    assert lib.tfnas_cell_plan(C.byref(_desc(ses=(0, 22)))) == -1    # SE width must be a multiple of 4
     bad = _desc()
     bad.G = 9
     assert lib.tfnas_cell_plan(C.byref(bad)) == -3

@@ -153,6 +153,8 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     for (int g = 0; g < d->G; ++g) {
         TfnasGroup& gr = d->g[g];
         if (gr.mc < 1 || (gr.k != 3 && gr.k != 5) || gr.se < 0) return TFNAS_EINVAL;
+        if (gr.se & 3) return TFNAS_EINVAL;       // SE widths are in_channels x {1, 2} in the search space; the excite
+                                                  // GEMMs move hidden units in quads
         gr.mcp = (gr.mc + 3) & ~3;
         // every group starts on a 128-byte line of the [pixels][M] rows (and M is a multiple of 32 floats, so every row
         // does too): the 32-channel segments the depthwise kernels move and the 64-column GEMM tiles are then whole
