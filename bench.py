@@ -14,6 +14,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 stream (tfnas_prof_* hooks), vs its algorithmic flops / HBM bytes (DESIGN.md section 5);
                 roofline.pair = the whole iteration pair against SURVEY.md 8(d)'s algorithmic floor
                 (t_lower_ms, achieved = t_lower / t, hbm_fraction vs F0, mfma_fraction of the 1x1 flops).
+  kernel_roofline  every modelled kernel family of one profiled pair: ms per pair, nearer bound, fraction of it.
+  retrain       BASELINE configs[4] at its own size: derived-network retrain step at 224x224, 256 images per GPU
+                (retrain_images_per_s; finiteness + bit-determinism checked).
   w_step_ms / a_step_ms   GPU time of the two kinds of step (HIP events on the launch stream, a few pairs after
                 the timed region).
   dropin_images_per_s     the same iteration pair written exactly like the reference's train_w_arch body
@@ -113,7 +116,41 @@ def family_algorithmic(fam, B):
             fl += f * launches
             by += b * launches
             n += kernels
+    # the stem cell (first_stem + second_stem as ONE TFNAS_MODE_STEM cell, G = 1: mid 32, 112x112, stride 1, oc 16) launches
+    # the same depthwise / project / pooling kernels: forward once per step (3 per pair; the w-step shares one stem
+    # evaluation between its two paths), backward and weight gradients in the 2 w-steps only (frozen weights in the alpha-step)
+    P = float(B) * 112 * 112
+    M, oc = 32.0, 16.0
+    stem = {'k_dw_fwd': (2.0 * P * M * 9.0, 4.0 * 2 * P * M, 3), 'k_dw_bwd_data': (2.0 * P * M * 9.0, 4.0 * 4 * P * M, 2),
+            'k_project_fwd': (2.0 * P * M * oc, 4.0 * (P * M + P * oc), 3),
+            'k_project_dgrad': (2.0 * P * M * oc, 4.0 * (2 * P * oc + P * M), 2),
+            'k_se_pool<bwd>': (8.0 * P * M, 4.0 * 2 * P * M, 2),
+            'k_project_wgrad': (2.0 * P * M * oc, 4.0 * (P * M + 2 * P * oc), 2),
+            'k_dw_wgrad': (2.0 * P * M * 9.0, 4.0 * 3 * P * M, 2)}.get(fam)
+    if stem is not None:
+        fl += stem[0] * stem[2]
+        by += stem[1] * stem[2]
+        n += stem[2]
     return fl, by, n
+
+
+def kernel_roofline(fam_ms, B):
+    """Every modelled kernel family of ONE profiled iteration pair against its own roofline: ms per pair (HIP events on the
+    launch streams, other streams running beside it in the w-step), algorithmic GB/s and TF/s over that time, the bound that
+    is nearer and the fraction of it."""
+    rows = []
+    for fam, (cnt, ms) in sorted(fam_ms.items(), key=lambda kv: -kv[1][1]):
+        if not cnt:
+            continue
+        alg = family_algorithmic(fam, B)
+        row = dict(family=fam, launches=int(cnt), ms_per_pair=round(ms, 3))
+        if alg is not None and ms > 0:
+            fl, by, _ = alg
+            tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+            fm, fh = tf / PEAK_FP32_MFMA_TF, gbs / PEAK_HBM_GBS
+            row.update(bound='mfma' if fm >= fh else 'hbm', frac=round(max(fm, fh), 4), tflops=round(tf, 2), gbs=round(gbs, 1))
+        rows.append(row)
+    return rows
 
 
 def pair_algorithmic(B, elt=4):
@@ -201,6 +238,70 @@ def dropin_pair(model, opt_w, opt_a, bw, ba, target_lat=15.0, lambda_lat=0.1, gr
                 p.data = F.log_softmax(p.detach().data, dim=-1)
 
 
+def _require_finite(model, what):
+    """A throughput number from a diverged run is worthless (NaN arithmetic runs at full speed)."""
+    bad = [n for n, p in model.named_parameters() if not bool(torch.isfinite(p).all())]
+    if bad:
+        raise RuntimeError('bench: non-finite parameters after %s: %s ...' % (what, bad[:3]))
+
+
+def retrain_leg(dev, batch=256, steps=10, warmup=3):
+    """BASELINE configs[4] at its own size on one GPU: the derived-network retrain step (train_eval.py:228-252: forward,
+    label-smoothed loss, backward, clip, SGD) at 224x224, 256 images per GPU, on the HIP path (tfnas_amd/model_eval.py).
+    Architecture: the all-candidate-1 full-depth network scaled to the 18 ms target of SURVEY 8(c).6 (the TF-NAS-A config
+    itself is not in the reference repository).  Checks: every parameter finite, and two runs from the same state are
+    bit-identical (deterministic kernels)."""
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g, model_eval as me
+    from tfnas_amd.elasticity import fit_mc_num_by_latency
+    from tfnas_amd.latency import load_lat_lookup
+    lut = load_lat_lookup('gpu')
+    mc = g.initial_mc_num_dddict()
+    arch = OrderedDict((st, OrderedDict((b, 1) for b in mc[st])) for st in mc)
+    mc, lat = fit_mc_num_by_latency(arch, mc, g.get_mc_num_dddict(g.make_mc_mask_dddict(), is_max=True),
+                                    g.make_lat_lookup_key_dddict(), lut, 18.0, list(mc.keys()), 1)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn(batch, 3, 224, 224, device=dev, generator=gen)
+    y = torch.randint(0, 1000, (batch,), device=dev, generator=gen)
+    crit = me.CrossEntropyLabelSmooth(1000, 0.1)
+
+    def fresh():
+        torch.manual_seed(0)
+        m = me.Network(1000, arch, mc, lut, 0.0, 0.0).to(dev)        # (no dropout / drop-connect draws: determinism check)
+        return m, torch.optim.SGD(m.parameters(), 0.2, momentum=0.9, weight_decay=4e-5)
+    finals = []
+    for _ in range(2):
+        m, opt = fresh()
+        for _ in range(2):
+            me.train_step(m, x, y, crit, opt, 5.0)
+        torch.cuda.synchronize()
+        finals.append([p.detach().clone() for p in m.parameters()])
+        del m, opt
+    deterministic = all(torch.equal(a, b) for a, b in zip(*finals))
+    del finals
+    torch.manual_seed(0)
+    model = me.Network(1000, arch, mc, lut, 0.2, 0.2).to(dev)
+    opt = torch.optim.SGD(model.parameters(), 0.2, momentum=0.9, weight_decay=4e-5)
+    for _ in range(warmup):
+        me.train_step(model, x, y, crit, opt, 5.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        me.train_step(model, x, y, crit, opt, 5.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _require_finite(model, 'the retrain leg')
+    out = dict(retrain_images_per_s=round(batch * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 2), batch_per_gpu=batch,
+               steps=steps, warmup=warmup, dtype='fp32', deterministic=bool(deterministic), image='224x224',
+               arch='all-op-1 full depth, widths scaled to 18 ms (%.3f ms in the LUT), dropout 0.2, drop-connect 0.2' % lat,
+               params_M=round(sum(p.numel() for p in model.parameters()) / 1e6, 3))
+    if not deterministic:
+        raise RuntimeError('bench: the retrain step is not bit-deterministic')
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_gpu(args):
     from tfnas_amd import Network, load_lat_lookup, geometry, search, _lib
     rank = int(os.environ.get('RANK', '0'))
@@ -275,10 +376,7 @@ def run_gpu(args):
         dt = float(t)
     dom = collect()[dominant]
     lib.tfnas_prof_enable(0)
-    # a throughput number from a diverged run is worthless (NaN arithmetic runs at full speed): every parameter must be finite
-    bad = [n for n, p in model.named_parameters() if not bool(torch.isfinite(p).all())]
-    if bad:
-        raise RuntimeError('bench: non-finite parameters after the timed region: %s ...' % bad[:3])
+    _require_finite(model, 'the timed region')
 
     # ---- after the timed region: GPU time of the w-step and the alpha-step (HIP events on the launch stream; the
     # w-step's side streams fork from and join it) over a few more pairs
@@ -337,6 +435,7 @@ def run_gpu(args):
                                              val[i % len(val)], noise)
             torch.cuda.synchronize()
             sweep.append(dict(widths=name, images_per_s=round(2.0 * B * 6 / (time.perf_counter() - t0), 1)))
+            _require_finite(m2, 'the width sweep (%s)' % name)
             if st2.runner is not None:
                 st2.runner.close()
             del st2, ow2, oa2, m2
@@ -366,6 +465,7 @@ def run_gpu(args):
             t = torch.tensor([dtb], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtb = float(t)
+        _require_finite(mb, 'the bf16 leg')
         bf16 = dict(value=round(2.0 * B * world * nb_ / dtb, 2), unit='images/s', ms_per_step=round(dtb / nb_ * 1e3, 3),
                     steps=nb_, warmup=wb_, dtype='bf16 storage of E/D/dZ/dEh, fp32 statistics / accumulation / weights',
                     parity='architecture-level gates of SURVEY 3.6 (tests/test_gpu_bf16.py); fp32 stays the parity mode')
@@ -373,6 +473,10 @@ def run_gpu(args):
             sb.runner.close()
         del sb, owb, oab, mb
         torch.cuda.empty_cache()
+
+    retrain = None
+    if world == 1 and args.retrain:
+        retrain = retrain_leg(dev)
 
     result = None
     if rank == 0:
@@ -422,8 +526,10 @@ def run_gpu(args):
                       roofline=roof, w_step_ms=round(w_ms, 3), a_step_ms=round(a_ms, 3),
                       all_images_per_s=round(3.0 * B * world * args.steps / dt, 2),
                       dropin_images_per_s=None if dropin is None else round(dropin, 2), width_sweep=sweep, bf16=bf16,
+                      retrain=retrain,
                       kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
-                                          if v[0]})
+                                          if v[0]},
+                      kernel_roofline=kernel_roofline(fam_ms, B))
     if dist.is_initialized():
         dist.destroy_process_group()
     return result
@@ -540,6 +646,8 @@ def main():
     ap.add_argument('--no-bf16', dest='bf16', action='store_false', help='skip the secondary bf16-storage line')
     ap.add_argument('--no-width-sweep', dest='width_sweep', action='store_false',
                     help='skip the BASELINE configs[3] width sweep (6 widths x 6 pairs after the timed region)')
+    ap.add_argument('--no-retrain', dest='retrain', action='store_false',
+                    help='skip the BASELINE configs[4] leg (derived-network retrain step, 256 images at 224x224)')
     ap.add_argument('--batch', type=int, default=128, help='images per GPU per step-half (BASELINE configs[1]: 128)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)

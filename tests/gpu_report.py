@@ -44,6 +44,7 @@ def main():
                 print('%-18s %-6s EXCEPTION %r' % (name, label, ex))
                 bad += 1
                 continue
+            res.pop('_details', None)
             w = hc.worst(res)
             bad += len(w)
             print('%-18s %-6s %s  (%.1fs)' % (name, label, 'OK' if not w else 'FAIL %d' % len(w), time.time() - t0))

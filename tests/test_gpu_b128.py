@@ -55,21 +55,21 @@ def test_cell_soft_mode_at_batch_128(ci):
         pytest.skip('the oracle of stage1.block1 at B=128 keeps ~40 GB of autograd state')
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     o, m, x, r, e = _cell_inputs(ci)
-    # ReLU cells (0, 1): gradients are compared outside the oracle's ReLU-kink elements (see hc.relu_kink_masks) --
-    # at this size dozens of the ~1e9 pre-activations sit within fp32 rounding of 0
-    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=4e-6)
-    assert not hc.worst(res), hc.worst(res)
-    assert res.get('kink_fraction', (0, 0))[1] < 0.05
+    # ReLU cells: cell 1 (E materialised) is compared strictly with the HIP launch's ReLU decisions replayed in the oracle;
+    # cell 0 runs E-free in soft mode (nothing to replay): gradients outside the oracle's near-kink elements, the mask validated
+    # against an fp64 run of the oracle (hc.fp64_kink_check) -- at this size dozens of the ~1e9 pre-activations sit within
+    # fp32 rounding of 0
+    res = hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=4e-6, max_kink_fraction=0.02)
+    print('B=128 cell %d soft: %s' % (ci, {k: v for k, v in res.items() if k.startswith(('relu_', 'kink_', 'fp64_'))}))
 
 
 @pytest.mark.parametrize('ci,idx', [(0, 1), (1, 5), (2, 6), (11, 3), (15, 7)])
 def test_cell_sampled_mode_with_weight_grads_at_batch_128(ci, idx):
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     o, m, x, r, e = _cell_inputs(ci)
-    res = hc.compare_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=4e-6)
-    # weight gradients are sums over 128*H*W pixels: fp32 accumulation order differs between oneDNN and the HIP
-    # split-K partials, so the relative part of the tolerance is what matters at this size
-    assert not hc.worst(res, rtol=2e-3), hc.worst(res, rtol=2e-3)
+    # strict north_star tolerance (1e-3 relative), ReLU decisions replayed -- no kink exemption, no allowance
+    res = hc.check_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=4e-6, rtol=1e-3)
+    print('B=128 cell %d op %d sampled: %s' % (ci, idx, {k: v for k, v in res.items() if k.startswith('relu_')}))
 
 
 def _pair(lut, seed=2, T=5.0):

@@ -40,32 +40,32 @@ def _inputs(cfg):
     return o, m, x, r, e
 
 
-# ReLU cells: elements downstream of a pre-activation within KINK_TAU of 0 in the oracle are compared for boundedness only
-# (tests/_hipcheck.py::relu_kink_masks): which side of relu'(0) such an element takes depends on the summation order of the
-# expand GEMM (real_s1b2_56 has 5.4 M pre-activations; one flipped when the K order inside a chunk changed)
+# ReLU cells (tests/_hipcheck.py::compare_cell): launches that materialise E are compared STRICTLY, with the HIP launch's own
+# ReLU decisions replayed in the oracle (which side of relu'(0) a pre-activation within fp32 rounding of 0 takes depends on the
+# summation order of the expand GEMM: real_s1b2_56 has 5.4 M pre-activations, one flipped when the K order inside a chunk
+# changed).  E-free launches (soft mode of the stride-2 ic <= 24 cells) cannot be replayed; there the gradients are compared
+# outside the elements downstream of an oracle pre-activation within KINK_TAU of 0, and that mask is validated against an fp64
+# run of the oracle (fp64_kink_check: every fp32/fp64 disagreement lies inside it).
 KINK_TAU = 4e-6
 
 
 @pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_soft_mode_all_stages(cfg):
     o, m, x, r, e = _inputs(cfg)
-    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=KINK_TAU)
-    assert not hc.worst(res), hc.worst(res)
+    hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=KINK_TAU, max_kink_fraction=0.01)
 
 
 @pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
 @pytest.mark.parametrize('idx', [0, 3, 5, 6])
 def test_sampled_mode_with_weight_grads(cfg, idx):
     o, m, x, r, e = _inputs(cfg)
-    res = hc.compare_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=KINK_TAU)
-    assert not hc.worst(res), hc.worst(res)
+    hc.check_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=KINK_TAU)
 
 
 def test_soft_mode_also_gives_weight_grads_when_asked():
     """autograd semantics: if weights require grad in soft mode, all 8 candidates get gradients."""
     o, m, x, r, e = _inputs(CONFIGS[0])
-    res = hc.compare_cell(o, m, x, r, e, list(range(8)), need_wgrad=True)
-    assert not hc.worst(res), hc.worst(res)
+    hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=True)
 
 
 def test_forward_is_deterministic_and_linear_in_mix_weights():

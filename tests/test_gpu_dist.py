@@ -80,3 +80,103 @@ def test_two_ranks_on_one_gpu_stay_bit_identical(tmp_path):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_two_rank_worker, args=(1, port, str(one)), nprocs=1, join=True)
     assert json.load(open(one / 'r0.json'))['sha'] != r0['sha']
+
+
+def _two_rank_oracle_worker(rank, world, port, outdir):
+    """ONE teacher-forced w-step + alpha-step at 4 images per rank; the post-step state goes to disk."""
+    import torch
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, 'tf-nas_amd'),):
+        sys.path.insert(0, p)
+    from tfnas_amd import Network, load_lat_lookup, geometry, search
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(2)
+    model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
+    model.set_temperature(5.0)
+    state = search.SearchState(model)
+    opt_w, opt_a = search.make_optimizers(model)
+    noise = search.NoiseSource(7)
+    g = torch.Generator().manual_seed(100)                              # same global batch everywhere; rank r takes its shard
+    X = torch.randn(4 * world, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 100, (4 * world,), generator=g)
+    xs, ys = X[4 * rank:4 * rank + 4].to(dev), Y[4 * rank:4 * rank + 4].to(dev)
+    search.w_step(state, xs, ys, opt_w, 5.0, noise.exp(dev), noise.rand_pos())
+    gidx = [int(c.last_idx) for c in model.cells()]
+    wsd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    _, _, lat, grads = search.a_step(state, xs, ys, opt_a, 15.0, 0.1, 5.0, noise.exp(dev), return_grads=True)
+    torch.cuda.synchronize()
+    torch.save(dict(after_w=wsd, arch=[p.detach().cpu().clone() for p in model.arch_parameters()],
+                    grads=[t.cpu() for t in grads], ridx=gidx, lat=float(lat)), os.path.join(outdir, 'o%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_gpu_step_equals_oracle_shardwise_average(tmp_path):
+    """world_size 2 on the GPU (gloo, both ranks on the box's single MI355X) through the whole HIP data-parallel path vs the
+    CPU oracle's SHARD-WISE AVERAGED step -- per-shard forward / backward with per-shard BatchNorm statistics, gradients
+    averaged, clip + optimizer step once (the reference of tests/test_dp_gloo.py, here at 4 images per rank): weights after
+    the w-step, unclipped averaged architecture gradients, architecture parameters after the alpha-step."""
+    import socket
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import torch.multiprocessing as mp
+    import tfnas_oracle as orc
+    from tfnas_amd import search
+    from tfnas_amd.latency import load_lat_lookup
+    world = 2
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_oracle_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / ('o%d.pt' % r)) for r in (0, 1))
+    assert r0['ridx'] == r1['ridx']
+    for k in r0['after_w']:
+        assert torch.equal(r0['after_w'][k], r1['after_w'][k]), k           # replicas bit-identical
+    # ---- the oracle's shard-wise averaged step
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    torch.manual_seed(2)
+    o = orc.Network(100, orc.initial_mc_num_dddict(), load_lat_lookup('gpu'))
+    o.set_temperature(5.0)
+    opt_w, opt_a = orc.make_optimizers(o)
+    noise = search.NoiseSource(7)
+    g = torch.Generator().manual_seed(100)
+    X = torch.randn(4 * world, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 100, (4 * world,), generator=g)
+    ng, rp = noise.exp('cpu'), noise.rand_pos()
+    orc._set_requires_grad(o, True, False)
+    opt_w.zero_grad()
+    for r in range(world):
+        xs, ys = X[4 * r:4 * r + 4], Y[4 * r:4 * r + 4]
+        lg, _ = o(xs, True, 'gumbel', exp_noise=ng)
+        lr_, _ = o(xs, True, 'random', rand_pos=rp)
+        ((F.cross_entropy(lg, ys) + F.cross_entropy(lr_, ys)) / world).backward()
+    assert [int(c.last_idx) for c in o.cells()] == r0['ridx']                # same sampled 'random' path
+    nn.utils.clip_grad_norm_(o.weight_parameters(), 5.0)
+    opt_w.step()
+    worst = 0.0
+    for k, a in o.state_dict().items():
+        b = r0['after_w'][k]
+        err, ref = float((b - a).abs().max()), float(a.abs().max())
+        assert err <= 1e-4 + 1e-3 * ref, (k, err, ref)
+        worst = max(worst, err)
+    na = noise.exp('cpu')
+    orc._set_requires_grad(o, False, True)
+    opt_a.zero_grad()
+    for r in range(world):
+        xs, ys = X[4 * r:4 * r + 4], Y[4 * r:4 * r + 4]
+        l, lat = o(xs, False, exp_noise=na)
+        ((F.cross_entropy(l, ys) + torch.abs(lat / 15.0 - 1.) * 0.1) / world).backward()
+    grads = [p.grad.detach().clone() for p in o.arch_parameters()]
+    nn.utils.clip_grad_norm_(o.arch_parameters(), 5.0)
+    opt_a.step()
+    for p in o.arch_parameters():
+        p.data = F.log_softmax(p.detach().data, dim=-1)
+    assert abs(float(lat) - r0['lat']) < 1e-3
+    for a, b in zip(grads, r0['grads']):
+        assert torch.allclose(b, a, atol=1e-4), float((b - a).abs().max())
+    for a, b in zip(o.arch_parameters(), r0['arch']):
+        assert torch.allclose(b, a.detach(), atol=1e-3)
+    print('2-rank GPU step vs oracle shard-wise average: worst |dw| %.3g' % worst)

@@ -43,8 +43,12 @@ def test_three_epochs_with_width_remasking(tmp_path):
                 assert torch.equal(sd3[key][off], sd2[key][off]), key        # masked-out rows are never touched
                 trained += int(not torch.equal(sd3[key][on], sd2[key][on]))
     assert 18 <= trained <= 18 * 6                                           # 3 steps x 2 sampled candidates per cell
-    for v in sd3.values():
+    for k, v in sd3.items():
         assert torch.isfinite(v).all()
+        # the store must own its tensors: a view into the epoch model's flat weight arena would drag the whole arena
+        # storage into every checkpoint
+        assert v.untyped_storage().nbytes() == v.numel() * v.element_size(), k
+    assert os.path.getsize(os.path.join(tmp_path, 'searched_model_03.pth.tar')) < 1.3 * sum(v.numel() * 4 for v in sd3.values()) + (1 << 20)
 
 
 def test_lut_builder_measures_monotone_plausible_latencies(tmp_path):

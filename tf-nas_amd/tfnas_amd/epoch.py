@@ -92,7 +92,9 @@ def scatter_weights_to_max(state_dict, model, mc_mask_dddict, prefix='module.'):
     cur = {prefix + k: v for k, v in net.state_dict().items()}
     for key in state_dict:
         if 'm_ops' not in key:
-            state_dict[key].data = cur[key].data.to(state_dict[key].device)
+            # clone: `cur` holds views into the model's flat WeightArena buffer; keeping a view would alias the store to the
+            # (dead) epoch model's arena and torch.save would serialise the whole arena storage per tensor
+            state_dict[key].data = cur[key].data.detach().clone().to(state_dict[key].device)
     for stage, blocks in mc_mask_dddict.items():
         for block, ops in blocks.items():
             for op_idx, mask in ops.items():
@@ -220,27 +222,35 @@ def search_epoch(epoch, state_dict, mc_mask_dddict, lat_lookup, train_queue, val
     dev = torch.device(device)
     stats = dict(epoch=epoch, lr=lr, T=T, steps=0)
     val_iter = iter(val_queue) if val_queue is not None else None
-    for step, (x_w, t_w) in enumerate(train_queue):
-        x_w, t_w = x_w.to(dev, non_blocking=True), t_w.to(dev, non_blocking=True)
-        if epoch < warmup_epochs:                              # train_wo_arch (train_search.py:318-354)
-            search.w_step(state, x_w, t_w, opt_w, grad_clip, noise.exp(dev), bi_sampling=False, group=group)
-        else:                                                  # train_w_arch (train_search.py:357-432)
-            search.w_step(state, x_w, t_w, opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
-            if step % 2 == 0:
-                try:
-                    x_a, t_a = next(val_iter)
-                except StopIteration:
-                    val_iter = iter(val_queue)
-                    x_a, t_a = next(val_iter)
-                la, ll, lat, _ = search.a_step(state, x_a.to(dev, non_blocking=True), t_a.to(dev, non_blocking=True), opt_a,
-                                               target_lat, lambda_lat, grad_clip, noise.exp(dev), group=group)
-                stats['last_lat'] = lat
-        stats['steps'] = step + 1
-    if 'last_lat' in stats:
-        stats['last_lat'] = float(stats['last_lat'])
-    if epochs - epoch < 5 and val_queue is not None:           # validation for the last 5 epochs (train_search.py:229-231)
-        stats['val_top1'], stats['val_top5'], stats['val_loss'] = search.validate(state, val_queue, noise=noise)
-    torch.cuda.synchronize(dev) if dev.type == 'cuda' else None
+    try:
+        for step, (x_w, t_w) in enumerate(train_queue):
+            x_w, t_w = x_w.to(dev, non_blocking=True), t_w.to(dev, non_blocking=True)
+            if epoch < warmup_epochs:                              # train_wo_arch (train_search.py:318-354)
+                search.w_step(state, x_w, t_w, opt_w, grad_clip, noise.exp(dev), bi_sampling=False, group=group)
+            else:                                                  # train_w_arch (train_search.py:357-432)
+                search.w_step(state, x_w, t_w, opt_w, grad_clip, noise.exp(dev), noise.rand_pos(), group=group)
+                if step % 2 == 0:
+                    try:
+                        x_a, t_a = next(val_iter)
+                    except StopIteration:
+                        val_iter = iter(val_queue)
+                        x_a, t_a = next(val_iter)
+                    la, ll, lat, _ = search.a_step(state, x_a.to(dev, non_blocking=True), t_a.to(dev, non_blocking=True), opt_a,
+                                                   target_lat, lambda_lat, grad_clip, noise.exp(dev), group=group)
+                    stats['last_lat'] = lat
+            stats['steps'] = step + 1
+        if 'last_lat' in stats:
+            stats['last_lat'] = float(stats['last_lat'])
+        if epochs - epoch < 5 and val_queue is not None:           # validation for the last 5 epochs (train_search.py:229-231)
+            stats['val_top1'], stats['val_top5'], stats['val_loss'] = search.validate(state, val_queue, noise=noise)
+        torch.cuda.synchronize(dev) if dev.type == 'cuda' else None
+    except BaseException:
+        # a failed step must not leak the path contexts (streams + ~130 events each) or leave the data-parallel segment hook
+        # armed with this epoch's state
+        if state.runner is not None:
+            state.runner.segment_hook = None
+            state.runner.close()
+        raise
     scatter_weights_to_max(state_dict, model, mc_mask_dddict)
     if epoch >= warmup_epochs:
         op_w, depth_w = get_op_and_depth_weights(model)
@@ -251,6 +261,7 @@ def search_epoch(epoch, state_dict, mc_mask_dddict, lat_lookup, train_queue, val
         log('epoch %d: lat %.4f -> %.4f (target %.4f), %d candidates re-masked' % (epoch, before, after, target_lat,
                                                                                   len(changed)))
     if state.runner is not None:
+        state.runner.segment_hook = None
         state.runner.close()
     return state_dict, mc_mask_dddict, stats
 

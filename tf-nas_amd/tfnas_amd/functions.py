@@ -152,6 +152,8 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
         check(_lib.lib(bool(d.stor)).tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                            ptr(stats), ptr(part), ptr(out), _stream(dev)), 'tfnas_mixedop_fwd')
     ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
+    if MixedOpFn.fwd_sink is not None:
+        MixedOpFn.fwd_sink.append(dict(plan=plan, d=d, ws=ws, E=E, D=D, stats=stats, fsmall=fsmall, shape=(N, d.H, d.W)))
     ctx.save_for_backward(xh, wmix, E, D, Pr, fsmall, stats, *params)
     return out.permute(0, 3, 1, 2)
 
@@ -275,6 +277,7 @@ class HeadFn(torch.autograd.Function):
 
 
 MixedOpFn.debug_sink = None      # tests set this to a list to capture backward scratch tensors
+MixedOpFn.fwd_sink = None        # ... and this one to capture the forward's saved tensors (E, D, statistics) per launch
 
 
 class ArchFn(torch.autograd.Function):

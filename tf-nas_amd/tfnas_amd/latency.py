@@ -14,6 +14,9 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 
 
 def load_lat_lookup(which='gpu'):
+    """'gpu' / 'cpu': the reference's tables (inference latency of the derived blocks on a Titan RTX / Xeon 6130);
+    'mi355x': measured by lut_builder.py on an MI355X -- NOTE it times the search net's *training-mode* forward (batch-statistic
+    BatchNorm, batch 32), so it ranks candidates by HIP training-forward time, not by deployment latency."""
     if which in ('gpu', 'cpu', 'mi355x'):      # gpu / cpu: the reference's tables; mi355x: measured here (lut_builder.py)
         path = os.path.join(_DATA, 'latency_%s.npz' % which)
     else:

@@ -12,6 +12,13 @@ The table has the reference's shape -- ``OrderedDict{'base': ms, key: OrderedDic
 interpolated linearly in between, the scheme the reference sketches in its commented-out ``convert_latency_lookup``
 (:494-518).  Widths <= in_channels are not reachable by the search (an MBConv has an expand convolution only when
 mid > in, layers.py:462; elasticity scaling never goes below max/2 = 2*in) and get the smallest measured value.
+
+WHAT THE TABLE MEANS (differs from the reference's): the timed launch sequence is the SEARCH net's sampled-mode forward --
+train-mode batch-statistic BatchNorm without affine parameters at batch 32 -- not the inference forward of the derived block
+(eval-mode affine BatchNorm folded into the convolutions) that the reference's pickles hold.  The latency term of the
+architecture step and elasticity scaling therefore steer towards "HIP training-forward time on MI355X"; relative candidate
+costs track deployment latency (same convolutions, same tensors), absolute values do not.  Use the reference's 'gpu' / 'cpu'
+tables when the target is the reference's deployment latency.
 """
 import ctypes as C
 import pickle
@@ -71,9 +78,10 @@ class _BlockTimer:
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            for _ in range(iters):
-                lib.tfnas_mixedop_fwd(*args)
+            rcs = [lib.tfnas_mixedop_fwd(*args) for _ in range(iters)]
             e1.record(stream)
+            for rc in rcs:
+                _lib.check(rc, 'tfnas_mixedop_fwd')
             e1.synchronize()
             times.append(e0.elapsed_time(e1) / iters)
         return float(np.median(times))

@@ -294,9 +294,10 @@ class SearchState:
         pending.append((host, ev, [h, -h]))
         self._dp_check = pending[-4:]
 
-    def fused_arch_step(self, opt_a, grad_clip, group=None):
+    def fused_arch_step(self, opt_a, grad_clip, group=None, reduce=True):
         """(all-reduce) + clip + Adam + log-softmax projection of all architecture parameters in ONE launch
-        (train_search.py:414-422).  Adam's moments live in two [n, 8] buffers that torch's optimizer state views."""
+        (train_search.py:414-422).  Adam's moments live in two [n, 8] buffers that torch's optimizer state views.
+        ``reduce=False``: the gradients were already averaged over ``group`` by the caller (no second collective)."""
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
@@ -331,7 +332,8 @@ class SearchState:
             raise RuntimeError('tfnas_amd: every architecture parameter needs a gradient in the architecture step')
         scale = 1.0
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1 or (world == 1 and dist.is_available() and dist.is_initialized() and FORCE_ALLREDUCE_AT_WORLD_1):
+        if reduce and (world > 1 or (world == 1 and dist.is_available() and dist.is_initialized()
+                                     and FORCE_ALLREDUCE_AT_WORLD_1)):
             allreduce_mean_(grads, group)                # 162 floats: one small message
         self._adam_t += 1
         lens = (C.c_int32 * n)(*[p.numel() for p in arch])
@@ -730,7 +732,7 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
         if return_grads:                        # (unclipped, but averaged over ranks like the legacy route returns them)
             allreduce_mean_([p.grad for p in state.arch if p.grad is not None], group)
             grads = [p.grad.detach().clone() for p in state.arch]
-            state.fused_arch_step(opt_a, grad_clip, None)
+            state.fused_arch_step(opt_a, grad_clip, group, reduce=False)
         else:
             grads = None
             state.fused_arch_step(opt_a, grad_clip, group)
@@ -825,7 +827,7 @@ class TfnasDataParallel(nn.Module):
 
     Gradient averaging across ranks is not done by hooks here: the search steps (``w_step`` / ``a_step``) reduce the
     sampled sub-network's gradients themselves (only ~1/4 of the parameters have a gradient in a step, and which ones is
-    known on the host before backward), see GradReducer."""
+    known on the host before backward): SearchState.dp_begin / fused_weight_step."""
 
     def __init__(self, module, device=None, process_group=None):
         super().__init__()

@@ -38,6 +38,11 @@ def pick_concurrent_streams(device, k, candidates=12, cycles=400000):
     whatever was found plus fresh streams when fewer than k qualify.  ~10-20 ms once per process."""
     device = torch.device(device)
     base = torch.cuda.current_stream(device)
+    # measured once per (device, current stream) and process: every epoch of epoch.search_epoch builds a new SearchState
+    key = (device.index if device.index is not None else torch.cuda.current_device(), base.cuda_stream, k)
+    hit = _PICKED.get(key)
+    if hit is not None:
+        return list(hit)
     pool = [torch.cuda.Stream(device=device) for _ in range(candidates)]
     chosen = []
     for s in pool:
@@ -51,7 +56,9 @@ def pick_concurrent_streams(device, k, candidates=12, cycles=400000):
             break
         if s not in chosen:
             chosen.append(s)
+    _PICKED[key] = list(chosen)
     return chosen
 
 
 _KEEP = []
+_PICKED = {}
