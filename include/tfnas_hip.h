@@ -91,7 +91,13 @@ typedef struct TfnasCellDesc {
     int32_t stor;             /* storage of the [pixels][M] stream tensors E, D, dZ, dEh: 0 = fp32 (the parity mode),
                                  1 = bf16 (throughput mode: BASELINE configs[1] "bf16"; statistics, accumulation and every
                                  other tensor stay fp32; tfnas_cell_ws sizes the four buffers accordingly)        [in] */
-    int32_t pad1, pad2;
+    int32_t xg;               /* 1: every group has its OWN input -- x and dx are [G][N*H*W][ic] (group g at g*N*H*W*ic) and
+                                 dx[g] receives group g's gradient only; 0: one shared input, dx summed over the groups.
+                                 Requires og = 1.                                                                  [in] */
+    int32_t og;               /* 1: every group has its OWN output -- out and dout are [G][N*Ho*Wo][oc], out[g] = BN3(project_g)
+                                 (+ x[g]), wmix must be NULL; 0: the groups are mixed into one output.  og = 1 with G = 2 runs
+                                 BOTH bi-sampling paths of a weight step (train_search.py:375-379) through one launch per kernel:
+                                 twice the workgroups per launch, half the launches, one dependency chain.           [in] */
     TfnasGroup g[TFNAS_MAX_GROUPS];
 } TfnasCellDesc;
 
@@ -105,7 +111,7 @@ typedef struct TfnasCellWs {
     uint64_t off_pooled, off_gate, off_hpre;
     uint64_t stats;    /* doubles stats1[M][2] | stats2[M][2] | stats3[G*oc][2]  (sum,sumsq) */
     uint64_t off_stats1, off_stats2, off_stats3;
-    uint64_t out;      /* floats  [N*Ho*Wo][oc]                                             */
+    uint64_t out;      /* floats  [N*Ho*Wo][oc]   ([G][N*Ho*Wo][oc] with og = 1)                    */
     /* backward scratch */
     uint64_t dZ;       /* floats  [N*Ho*Wo][M]                                              */
     uint64_t dEh;      /* floats  [N*H*W][M]                                                */
@@ -121,7 +127,7 @@ typedef struct TfnasCellWs {
                           Doubled when d.need_wgrad is set: tfnas_mixedop_bwd runs the weight-gradient kernels on
                           a library-owned side stream (forked from / joined to `stream` inside the call) and gives
                           them the second half.                                                              */
-    uint64_t dx;       /* floats  [N*H*W][ic]                                               */
+    uint64_t dx;       /* floats  [N*H*W][ic]     ([G][N*H*W][ic] with xg = 1)                      */
     uint64_t dxp;      /* floats  split-K partial tiles of the expand dgrad (may be tiny); pass NULL to disable */
 } TfnasCellWs;
 
@@ -293,7 +299,10 @@ typedef struct TfnasPathDesc {
     int32_t soft;           /* 1: cells carry G = 8 groups, wmix/cell_lat are consumed and d wmix / d cell_lat produced */
     int32_t need_dx0;       /* backward produces the gradient of the path input                               */
     int32_t efree_mask_lo;  /* bit c set: cell c runs E-free (E never materialised; needs tfnas_efree_supported) */
-    int32_t pad0;
+    int32_t dual;           /* 1 (sampled mode only): BOTH bi-sampling paths in this one descriptor -- every cell carries G = 2
+                               groups (group 0 = the 'gumbel' candidate, group 1 = the 'random' one) with og = 1 and, except the
+                               first cell (both paths read the same stem output), xg = 1.  Every tensor between cells is
+                               [2][N][H][W][C]; out / dout are [2][out_count/2], dx0 is ONE tensor (the sum over both paths). */
     TfnasStage stage[TFNAS_MAX_STAGES];
     TfnasCellDesc cell[TFNAS_MAX_CELLS];   /* [in] fields + weight / gradient pointers bound; N, H, W chained by plan */
 } TfnasPathDesc;
@@ -304,7 +313,7 @@ typedef struct TfnasPathWs {
     uint64_t saved;         /* forward results kept for backward (E, D, Pr, small tensors, statistics, cell / stage outputs) */
     uint64_t scratch;       /* forward + backward scratch (partials, dZ, dEh, gradient ring)                  */
     uint64_t total;         /* saved + scratch                                                                */
-    uint64_t out_count;     /* elements of the path output [N][Ho][Wo][oc] of the last stage                  */
+    uint64_t out_count;     /* elements of the path output [N][Ho][Wo][oc] of the last stage (x 2 in dual mode) */
     int32_t out_h, out_w, out_c, pad;
 } TfnasPathWs;
 

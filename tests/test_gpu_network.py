@@ -178,8 +178,10 @@ def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
     per-cell route on one stream vs the interleaved path level on two (+ two weight-gradient streams), same torch.optim tail."""
     from tfnas_amd import search
     res = []
-    old = search.FUSED_OPT
+    old, old_d = search.FUSED_OPT, search.DUAL_PATHS
     search.FUSED_OPT = False
+    search.DUAL_PATHS = False              # (the two-stream route of round 2; the dual mode changes summation orders and is
+                                           #  compared with it in tests/test_gpu_paths.py)
     for overlap in (False, True):
         _, m = _pair(lut)
         st = search.SearchState(m)
@@ -193,7 +195,7 @@ def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
             search.w_step(st, x, y, ow, 5.0, noise_g=ng, rand_pos=rp, overlap_paths=overlap)
         torch.cuda.synchronize()
         res.append([p.detach().clone() for p in m.weight_parameters()])
-    search.FUSED_OPT = old
+    search.FUSED_OPT, search.DUAL_PATHS = old, old_d
     for a, b in zip(*res):
         assert torch.equal(a, b)
 
@@ -252,11 +254,35 @@ def test_width_sweep_matches_oracle(lut, widths):
     for (k, a), (_, b) in zip(o.named_parameters(), m.named_parameters()):
         if k.endswith('log_alphas') or k.endswith('betas'):
             assert torch.allclose(b.grad.cpu(), a.grad, atol=1e-4), (k, float((b.grad.cpu() - a.grad).abs().max()))
-    # a sampled w-step path (weight gradients) at the same widths
+    # a sampled w-step path (weight gradients) at the same widths.  ReLU layers (stems, stage1): a pre-activation within
+    # fp32 rounding of 0 can take the other side of relu'(0) in two implementations, which moves single entries of a weight
+    # gradient by O(1e-2) of the tensor's scale (observed: 1.9e-2 on stage1.block2 with target-18 widths).  Instead of a
+    # loose gate on those tensors, the HIP forward runs FIRST, its own ReLU decisions are rebuilt from the tensors it saved
+    # and replayed in the oracle (_hipcheck.hip_relu_masks / ReluInjector): every tensor then meets the strict gate, and a
+    # replayed decision may differ from the oracle's own only where the oracle's pre-activation is within 4e-5 of 0.
+    import _hipcheck as hc
+    from tfnas_amd.functions import MixedOpFn
     for p in o.weight_parameters() + m.weight_parameters():
         p.requires_grad = True
-    so, _ = o(x, True, 'gumbel', exp_noise=noise)
+    MixedOpFn.fwd_sink = []
     sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    torch.cuda.synchronize()
+    recs, MixedOpFn.fwd_sink = MixedOpFn.fwd_sink, None
+    masks = []
+    for rec in recs:                                       # launch order == module order: stem cell, stage1.block1, ...
+        if rec['plan'].act != 'relu':
+            continue
+        for blk, (m1, m2) in zip(rec['plan'].blocks, hc.hip_relu_masks(rec)):
+            masks += [m1, m2] + ([None] if blk.se_channels else [])
+    assert len(masks) >= 8                                 # stem (3 sites) + two stage1 cells (2-3 sites each)
+    inj = hc.ReluInjector(masks)
+    orc.RELU_HOOK = inj
+    try:
+        so, _ = o(x, True, 'gumbel', exp_noise=noise)
+    finally:
+        orc.RELU_HOOK = None
+    inj.done()
+    assert inj.max_abs_at_flip <= 4e-5, inj.max_abs_at_flip
     assert torch.allclose(sm.cpu(), so, atol=1e-3, rtol=1e-3)
     torch.nn.functional.cross_entropy(so, y).backward()
     torch.nn.functional.cross_entropy(sm, y.cuda()).backward()
@@ -264,16 +290,7 @@ def test_width_sweep_matches_oracle(lut, widths):
         if a.grad is None or k.endswith('log_alphas') or k.endswith('betas'):
             continue
         err, ref = float((b.grad.cpu() - a.grad).abs().max()), float(a.grad.abs().max())
-        # ReLU layers (stems, stage1) at batch 2: a pre-activation within fp32 rounding of 0 flips relu'(0) between the two
-        # implementations; that moves single entries of a weight gradient by up to ~2e-2 of the tensor's scale (observed:
-        # 1.9e-2 on stage1.block2 with target-18 widths, while every stage of the same cells passes the kink-aware cell
-        # comparison of _hipcheck.relu_kink_masks and nothing on the swish stages exceeds 1e-4).  Judge those tensors by
-        # their relative L2 error instead of the worst entry.
-        if k.startswith('first_stem') or k.startswith('second_stem') or k.startswith('stage1'):
-            rel = float((b.grad.cpu() - a.grad).norm() / a.grad.norm().clamp_min(1e-12))
-            assert rel <= 1e-2, (k, rel)
-        else:
-            assert err <= 2e-5 + 2e-3 * ref, (k, err, ref)
+        assert err <= 2e-5 + 2e-3 * ref, (k, err, ref, inj.flips)
     o.reset_switches(); m.reset_switches()
 
 

@@ -146,6 +146,12 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
     if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
     if (d->has_res && (d->ic != d->oc || d->stride != 1)) return TFNAS_EINVAL;
+    // per-group outputs / inputs (both bi-sampling paths in one launch): MixedOP cells only; per-group inputs need per-group
+    // outputs; a residual cell with per-group outputs needs per-group inputs too (out[g] = ... + x[g])
+    if ((d->xg != 0 && d->xg != 1) || (d->og != 0 && d->og != 1)) return TFNAS_EINVAL;
+    if ((d->xg || d->og) && d->mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;
+    if (d->xg && !d->og) return TFNAS_EINVAL;
+    if (d->og && !d->xg && d->has_res) return TFNAS_EINVAL;
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
     d->Wo = (d->W - 1) / d->stride + 1;
@@ -199,7 +205,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_stats2 = 2 * M;
     ws->off_stats3 = 4 * M;
     ws->stats = 4 * M + 2 * G * oc;
-    ws->out = Po * oc;
+    ws->out = (d->og ? G : 1) * Po * oc;
     ws->dZ = (Po * M + sdiv - 1) / sdiv;
     ws->dEh = (P * M + sdiv - 1) / sdiv;
     ws->off_dgate = 0;
@@ -214,10 +220,10 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_red1 = ws->off_red2 + 2 * M;
     ws->red = ws->off_red1 + 2 * M;
     ws->part = (d->need_wgrad ? 2 : 1) * (uint64_t)TFNAS_PART_ALLOC;   // second half: weight-gradient side stream
-    ws->dx = P * d->ic;
+    ws->dx = (d->xg ? G : 1) * P * d->ic;
     {
         const int ns = d->mode == TFNAS_MODE_STEM ? 1 : expand_dgrad_splits(*d);
-        ws->dxp = ns > 1 ? (uint64_t)ns * P * d->ic : 4;   /* split-K partials of the expand dgrad */
+        ws->dxp = ns > 1 ? (uint64_t)ns * (d->xg ? G : 1) * P * d->ic : 4;   /* split-K partials of the expand dgrad */
     }
     return 0;
 }
@@ -383,6 +389,7 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     if (!dp || !x || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (d.og && wmix) return TFNAS_EINVAL;                   // per-group outputs are not mixed
     if (!E && !efree_supported(d)) return TFNAS_ENULL;       // E may be omitted only in E-free mode (tfnas_efree_supported)
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
@@ -423,7 +430,7 @@ extern "C" int tfnas_mbconv_fwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
                                 void* stream) {
     if (!dp || !bn || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
-    if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    if (d.mode == TFNAS_MODE_HEAD || d.G != 1 || d.xg || d.og) return TFNAS_EINVAL;
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     CellFwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, part, out};

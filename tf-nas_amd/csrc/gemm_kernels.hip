@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7, nchunks = (ic + 15) >> 4;
     const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
+    if (!STEM && d.xg) x += (size_t)g * P * ic;            // every group has its own input (the two bi-sampling paths)
 
     float cs[NT], cq[NT];
 #pragma unroll
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
     __syncthreads();
+    if (d.og) dout += (size_t)g * Po * oc;                 // every group has its own output gradient
 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
     const int r0 = blockIdx.x * rows_per_split, r1 = min(Po, r0 + rows_per_split);
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    if (d.og) dout += (size_t)g * Po * oc;
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
     // A thread stages the same 4 mid channels (A) and the same 4 output channels per B item in every K-chunk; only the
@@ -567,12 +570,24 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7;
     const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
+    // xg = 1 (every group has its own input, the two bi-sampling paths): blockIdx.z = group * nsplit + split; the K range is
+    // that group's mid channels (+ its own x / -G chunks), all operand / result pointers move to the group's slice
+    const int gsel = d.xg ? (int)blockIdx.z / nsplit : -1;
+    const int zs = d.xg ? (int)blockIdx.z - gsel * nsplit : (int)blockIdx.z;
     int mchunks = 0;
-    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    if (gsel >= 0) mchunks = (d.g[gsel].mcp + 15) >> 4;
+    else for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
     const int nchunks_all = mchunks + ((ic + 15) >> 4);      // mid-channel chunks, then the x / -G chunks
     const int per = (nchunks_all + nsplit - 1) / nsplit;
-    const int cbeg = blockIdx.z * per;
+    const int cbeg = zs * per;
     const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
+    if (gsel > 0) {
+        x += (size_t)gsel * P * ic;
+        dx += (size_t)gsel * P * ic;
+        gram += (size_t)gsel * (size_t)(ic + 4) * ic;
+        if (dout) dout += (size_t)gsel * P * d.oc;           // (only read by residual cells: ic == oc, P == Po)
+        if (add_src) add_src += (size_t)gsel * P * ic;
+    }
     float* __restrict__ dst = nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx;
     const bool add_res = d.has_res && nsplit == 1;
     const bool add_sink = add_src != nullptr && nsplit == 1;
@@ -605,11 +620,13 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
                 return;
             }
             int g = 0;
-            for (; g < d.G - 1; ++g) {
-                const int t = (d.g[g].mcp + 15) >> 4;
-                if (c < t) break;
-                c -= t;
-            }
+            if (gsel >= 0) g = gsel;
+            else
+                for (; g < d.G - 1; ++g) {
+                    const int t = (d.g[g].mcp + 15) >> 4;
+                    if (c < t) break;
+                    c -= t;
+                }
             is_x = false;
             k0 = c * 16;
             klim_a = d.g[g].mcp;
@@ -668,6 +685,14 @@ __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float*
     const float sink_w = add_src ? add_scale[0] : 0.f;
     const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
     const int iq = d.ic / 4;
+    if (d.xg) {                                              // blockIdx.y = group: its own partial tiles, operator, gradient slice
+        const size_t g = blockIdx.y;
+        dxp += g * (size_t)nsplit * n4 * 4;
+        gram += g * (size_t)(d.ic + 4) * d.ic;
+        dx += g * n4 * 4;
+        if (dout) dout += g * n4 * 4;
+        if (add_src) add_src += g * n4 * 4;
+    }
     const float* __restrict__ bias = gram + (size_t)d.ic * d.ic;
     float sumw = 1.f;
     if (wmix) {
@@ -689,14 +714,19 @@ __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float*
 // columns = input channels, K = all mid channels of all groups, split over blockIdx.x (k_reduce_rows sums the splits).
 template <int NT>
 __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const float* __restrict__ cb1, int chunks_per_split,
-                                                     float* __restrict__ part) {
+                                                     int nsplit, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     const int ic = d.ic;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.z * T::BN;
+    // xg = 1: one operator PER GROUP (every group back-propagates into its own input): blockIdx.x = group * nsplit + split,
+    // partial tile of (group, split) at part[blockIdx.x]
+    const int gsel = d.xg ? (int)blockIdx.x / nsplit : -1;
+    const int xs = d.xg ? (int)blockIdx.x - gsel * nsplit : (int)blockIdx.x;
     int mchunks = 0;
-    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
-    const int cbeg = blockIdx.x * chunks_per_split;
+    if (gsel >= 0) mchunks = (d.g[gsel].mcp + 15) >> 4;
+    else for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    const int cbeg = xs * chunks_per_split;
     const int nchunks = max(0, min(mchunks, cbeg + chunks_per_split) - cbeg);
     const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
@@ -707,11 +737,13 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
     auto locate = [&](int c, int& g, int& k0) {
         c += cbeg;
         g = 0;
-        for (; g < d.G - 1; ++g) {
-            const int t = (d.g[g].mcp + 15) >> 4;
-            if (c < t) break;
-            c -= t;
-        }
+        if (gsel >= 0) g = gsel;
+        else
+            for (; g < d.G - 1; ++g) {
+                const int t = (d.g[g].mcp + 15) >> 4;
+                if (c < t) break;
+                c -= t;
+            }
         k0 = c * 16;
     };
     auto fa = [&](int c, int kl, int m) -> f32x4 {       // A(m..m+3, k) = s_k W[k][m..m+3]; row ic = coef_k
@@ -774,6 +806,7 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
     const int r0 = blockIdx.x * rows_per_split, r1 = min(P, r0 + rows_per_split);
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
+    if (!STEM && d.xg) x += (size_t)g * P * ic;
 
     // per-thread constants of the K loop (see k_project_wgrad): the thread's 4 mid channels and its BN1-backward constants,
     // folded:  de = rstd (deh - t1 - (E - mu) rstd t2)  =  rstd deh - rstd t1 - (E - mu) (rstd^2 t2)
@@ -1070,10 +1103,14 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
 // K-splits of expand dgrad: only when the (row tile x column tile) grid cannot fill the chip
 int expand_dgrad_splits(const TfnasCellDesc& d) {
     const int nt = pick_nt(d.ic, kNtSmall, 6);
-    const int tiles = cdiv(d.N * d.H * d.W, 128) * cdiv(d.ic, 16 * nt);
+    const int tiles = cdiv(d.N * d.H * d.W, 128) * cdiv(d.ic, 16 * nt) * (d.xg ? d.G : 1);
     if (tiles >= 512) return 1;
     int nchunks = 0;
-    for (int g = 0; g < d.G; ++g) nchunks += cdiv(d.g[g].mcp, 16);
+    if (d.xg) {                                       // per-group K ranges: the narrowest group bounds the split count
+        nchunks = 1 << 30;
+        for (int g = 0; g < d.G; ++g) nchunks = cdiv(d.g[g].mcp, 16) < nchunks ? cdiv(d.g[g].mcp, 16) : nchunks;
+    } else
+        for (int g = 0; g < d.G; ++g) nchunks += cdiv(d.g[g].mcp, 16);
     int ns = cdiv(1024, tiles);
     if (ns > 16) ns = 16;
     if (ns > nchunks / 4) ns = nchunks / 4;      // at least 4 K-chunks per split
@@ -1081,28 +1118,32 @@ int expand_dgrad_splits(const TfnasCellDesc& d) {
 }
 
 // floats of the correction operator G | b
-size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.ic + 4) * d.ic; }
+size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.xg ? d.G : 1) * (size_t)(d.ic + 4) * d.ic; }
 
 // G | b -> gram ([ic+4][ic] floats); `scratch` holds the K-split partials (scratch_floats available)
 int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
                        hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
-    const size_t gsz = expand_gram_floats(d);
-    int mchunks = 0;
-    for (int g = 0; g < d.G; ++g) mchunks += cdiv(d.g[g].mcp, 16);
+    const int ng = d.xg ? d.G : 1;                                // operators to build (one per group with per-group inputs)
+    const size_t gsz = (size_t)(d.ic + 4) * d.ic;
+    int mchunks = 0;                                              // K-chunks of one operator (xg: of the widest group)
+    for (int g = 0; g < d.G; ++g) {
+        const int c = cdiv(d.g[g].mcp, 16);
+        mchunks = d.xg ? (c > mchunks ? c : mchunks) : mchunks + c;
+    }
     const int mtiles = cdiv(d.ic + 1, 128), ntiles = cdiv(d.ic, 16 * nt);
-    int splits = cdiv(512, mtiles * ntiles);
+    int splits = cdiv(512, mtiles * ntiles * ng);
     if (splits > mchunks / 4) splits = mchunks / 4;               // at least 4 K-chunks per split
-    if ((size_t)splits > scratch_floats / gsz) splits = (int)(scratch_floats / gsz);
+    if ((size_t)splits * ng > scratch_floats / gsz) splits = (int)(scratch_floats / gsz / ng);
     if (splits < 1) splits = 1;
-    if (scratch_floats < gsz) return TFNAS_ERANGE;
+    if (scratch_floats < gsz * ng) return TFNAS_ERANGE;
     const int cps = cdiv(mchunks, splits);
     splits = cdiv(mchunks, cps);
-    dim3 grid(splits, mtiles, ntiles);
-    DISPATCH_NT(nt, { hipLaunchKernelGGL(k_expand_gram<NT>, grid, dim3(256), 0, s, d, cb1, cps, scratch); })
+    dim3 grid(splits * ng, mtiles, ntiles);
+    DISPATCH_NT(nt, { hipLaunchKernelGGL(k_expand_gram<NT>, grid, dim3(256), 0, s, d, cb1, cps, splits, scratch); })
     _prof.stop();
-    return launch_reduce_rows(scratch, splits, (int)gsz, gsz, nullptr, gram, s);
+    return launch_reduce_rows(scratch, splits, (int)gsz, gsz, nullptr, gram, s, ng, (size_t)splits * gsz, gsz);
 }
 
 int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
@@ -1112,7 +1153,8 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit, 1u << 30, gemm_slots(nt), 4096), tiles, nsplit);
+    const int ng = d.xg ? d.G : 1;
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit * ng, 1u << 30, gemm_slots(nt), 4096), tiles, nsplit * ng);
     DISPATCH_NT(nt, {
         hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit,
                            add_src, add_scale);
@@ -1123,7 +1165,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
         const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
         size_t blocks = cdiv64(n4, 256 * 2);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx,
+        hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks, ng), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx,
                            add_src, add_scale);
     }
     return (int)hipGetLastError();

@@ -67,8 +67,10 @@ int launch_head_pool(const TfnasCellDesc& d, const float* E, const double* stats
 int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1, const float* dpooled, float* dEh,
                     double* red1, float* part, hipStream_t s);
 // out[c] = sum_{b<nb} part[b*stride + c]  (double and/or float output); the deterministic replacement of atomics
+// nbatch > 1: `nbatch` independent reductions in one launch (blockIdx.y): batch b reads part + b*in_stride and writes
+// out + b*out_stride
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
-                       hipStream_t s);
+                       hipStream_t s, int nbatch = 1, size_t in_stride = 0, size_t out_stride = 0);
 /* One `part` scratch region = TFNAS_PART_ALLOC floats (16 MiB): TFNAS_PART_FLOATS for per-workgroup partial rows / split-K
    tiles, then TFNAS_TAIL_SLOTS ticket counters of the "last workgroup reduces" epilogues (gemm_core.h: tail_reduce_cols).
    The counters must be ZERO when the region is first handed to the library (tfnas_hip.h) and are left zero by every launch. */

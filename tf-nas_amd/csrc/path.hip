@@ -86,11 +86,17 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         nc += sg.ncell;
     }
     if (nc != pd.ncell) return TFNAS_EINVAL;
+    if (pd.dual != 0 && pd.dual != 1) return TFNAS_EINVAL;
+    // dual: both bi-sampling paths in one descriptor (sampled mode; the path input is shared, so the first stage's input
+    // cannot itself be a depth choice of two different paths)
+    if (pd.dual && (pd.soft || pd.efree_mask_lo || pd.stage[0].start_res == 0)) return TFNAS_EINVAL;
     // cells: chain the geometry, plan, size
     for (int i = 0; i < pd.ncell; ++i) {
         TfnasCellDesc& d = pd.cell[i];
         if (d.mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;
-        if (!pd.soft && d.G != 1) return TFNAS_EINVAL;           // a sampled path evaluates one candidate per cell
+        if (!pd.soft && d.G != (pd.dual ? 2 : 1)) return TFNAS_EINVAL;   // a sampled path evaluates one candidate per cell
+        d.og = pd.dual ? 1 : 0;                                   // (dual: two, each with its own output ...
+        d.xg = (pd.dual && i > 0) ? 1 : 0;                        //  ... and, after the first cell, its own input)
         if (i > 0) {
             const TfnasCellDesc& p = pd.cell[i - 1];
             if (d.ic != p.oc) return TFNAS_EINVAL;
@@ -139,7 +145,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         const TfnasStage& sg = pd.stage[st];
         const TfnasCellDesc& l = pd.cell[sg.first_cell + sg.ncell - 1];
         StageOff& o = c.so[st];
-        o.count = (uint64_t)l.N * l.Ho * l.Wo * l.oc;
+        o.count = (uint64_t)(pd.dual ? 2 : 1) * l.N * l.Ho * l.Wo * l.oc;
         o.sink_out = ~(uint64_t)0;
         if (st + 1 < pd.nstage) { o.sink_out = off; off += up(o.count); }
         o.bw = off; off += ALIGN;

@@ -111,6 +111,25 @@ __global__ __launch_bounds__(256) void k_mix_fwd(TfnasCellDesc d, const float* _
         tab[i] = make_float2(c.x, c.y * (wmix ? wmix[i / oc] : 1.f));
     }
     __syncthreads();
+    if (d.og) {
+        // every group has its own output (the two bi-sampling paths in one launch): out[g] = BN3(Pr[g]) (+ x[g])
+        const size_t per = (size_t)Po * OQ, tot = per * G;
+        for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
+            const int g = (int)(idx / per);
+            const size_t r = idx - (size_t)g * per, p = r / OQ;
+            const int o = (int)(r % OQ) * 4;
+            const f32x4 pr = ld4(Pr + ((size_t)g * Po + p) * oc + o);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = tab[g * oc + o + j];
+                v[j] = (pr[j] - t.x) * t.y;
+            }
+            if (d.has_res) v += ld4(x + ((d.xg ? (size_t)g * Po : 0) + p) * d.ic + o);
+            st4(out + ((size_t)g * Po + p) * oc + o, v);
+        }
+        return;
+    }
     const size_t total = (size_t)Po * OQ;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const size_t p = idx / OQ;
@@ -137,10 +156,19 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
                                                        const float* __restrict__ x, float* __restrict__ part,
                                                        int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int oc = d.oc, G = d.G, TQ = oc >> 2, RP = 256 / TQ;
+    const int oc = d.oc, TQ = oc >> 2, RP = 256 / TQ;
     const int Po = d.N * d.Ho * d.Wo;
+    // og = 1 (every group has its own output gradient): blockIdx.y = group, a G = 1 problem on that group's slices; the
+    // partial row keeps the [G*oc][2] | [oc] layout (the resdot part is not used in that mode)
+    const int gb = d.og ? (int)blockIdx.y : 0, G = d.og ? 1 : d.G, Gall = d.G;
+    if (d.og) {
+        dout += (size_t)gb * Po * oc;
+        Pr += (size_t)gb * Po * oc;
+        stats3 += 2 * (size_t)gb * oc;
+        if (d.xg) x += (size_t)gb * Po * d.ic;
+    }
     float2* tab = reinterpret_cast<float2*>(lds);                    // [G*oc] (mean3, rstd3)
-    f32x4* buf = reinterpret_cast<f32x4*>(lds + 2 * G * oc);         // [256]
+    f32x4* buf = reinterpret_cast<f32x4*>(lds + 2 * Gall * oc);      // [256]
     for (int i = threadIdx.x; i < G * oc; i += 256) tab[i] = bn_consts(stats3 + 2 * (size_t)i, 1.0 / (double)Po, d.eps);
     __syncthreads();
     const int tid = threadIdx.x, oq = tid % TQ, pr = tid / TQ, o = 4 * oq;
@@ -168,10 +196,10 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
         }
     }
     // this workgroup's row of the partials matrix: [G*oc][2] (S1,S2) followed by [oc] partial <dout,x> sums
-    float* prow = part + (size_t)blockIdx.x * (2 * G * oc + oc);
+    float* prow = part + (size_t)blockIdx.x * (2 * Gall * oc + oc) + 2 * (size_t)gb * oc;
     s1 = reduce_rows(s1, buf, pr, oq, RP, TQ, active);
     sx = reduce_rows(sx, buf, pr, oq, RP, TQ, active);
-    if (active && pr == 0) st4(prow + 2 * G * oc + o, sx);
+    if (active && pr == 0 && gb == 0) st4(prow + 2 * Gall * oc + o, sx);
 #pragma unroll
     for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
         if (g < G) {
@@ -493,9 +521,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(TfnasCellDesc d, const float* 
 // weight-gradient partials (<= 128 rows of 10^4..10^5 columns), where the scalar version read 32-byte pieces of each row.
 template <int CL>
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int nb, int ncols, size_t stride,
-                                                     double* __restrict__ out_d, float* __restrict__ out_f) {
+                                                     double* __restrict__ out_d, float* __restrict__ out_f,
+                                                     size_t in_stride, size_t out_stride) {
     constexpr int RL = 256 / CL;
     __shared__ double buf[RL][CL + 1];
+    part += blockIdx.y * in_stride;
+    if (out_d) out_d += blockIdx.y * out_stride;
+    if (out_f) out_f += blockIdx.y * out_stride;
     const int tid = threadIdx.x, cl = tid % CL, rl = tid / CL;
     const int c = blockIdx.x * CL + cl;
     double s = 0.0;
@@ -520,8 +552,12 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void k_reduce_rows_wide(const float* __restrict__ part, int nb, int ncols, size_t stride,
-                                                          double* __restrict__ out_d, float* __restrict__ out_f) {
+                                                          double* __restrict__ out_d, float* __restrict__ out_f,
+                                                          size_t in_stride, size_t out_stride) {
     __shared__ double buf[8][128 + 4];
+    part += blockIdx.y * in_stride;
+    if (out_d) out_d += blockIdx.y * out_stride;
+    if (out_f) out_f += blockIdx.y * out_stride;
     const int tid = threadIdx.x, cq = tid & 31, rl = tid >> 5;
     const int c = blockIdx.x * 128 + 4 * cq;                  // ncols % 4 == 0: a quad is inside or outside as a whole
     double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -606,15 +642,19 @@ int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const d
 }
 
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
-                       hipStream_t s) {
+                       hipStream_t s, int nbatch, size_t in_stride, size_t out_stride) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
-    const bool al4 = (ncols & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)part & 15) == 0;
+    const bool al4 = (ncols & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)part & 15) == 0 && (in_stride & 3) == 0;
+    const unsigned nby = nbatch > 1 ? (unsigned)nbatch : 1u;
     if (al4 && nb <= 128 && ncols >= 1024)
-        hipLaunchKernelGGL(k_reduce_rows_wide, dim3(cdiv(ncols, 128)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+        hipLaunchKernelGGL(k_reduce_rows_wide, dim3(cdiv(ncols, 128), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d,
+                           out_f, in_stride, out_stride);
     else if (ncols <= 2048 && nb > 256)
-        hipLaunchKernelGGL(k_reduce_rows<4>, dim3(cdiv(ncols, 4)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+        hipLaunchKernelGGL(k_reduce_rows<4>, dim3(cdiv(ncols, 4), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
+                           in_stride, out_stride);
     else
-        hipLaunchKernelGGL(k_reduce_rows<8>, dim3(cdiv(ncols, 8)), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f);
+        hipLaunchKernelGGL(k_reduce_rows<8>, dim3(cdiv(ncols, 8), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
+                           in_stride, out_stride);
     return (int)hipGetLastError();
 }
 
@@ -649,7 +689,7 @@ int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s) {
     ProfScope _prof(TK_MIX_FWD, s);
-    const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4);
+    const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4) * (d.og ? d.G : 1);
     size_t blocks = cdiv64(total, 256 * 4);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -670,7 +710,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
     if (rpb < 8 * RP) rpb = 8 * RP;
     const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
     const int gx = cdiv(Po, rpb);
-    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
+    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx, d.og ? d.G : 1), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
     _prof.stop();
     return launch_reduce_rows(part, gx, ncols, (size_t)ncols, red3, nullptr, s);
 }

@@ -32,7 +32,7 @@ class TfnasCellDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
                                           'Ho', 'Wo', 'M', 'SE')]
                 + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
-                   ('stor', C.c_int32), ('pad1', C.c_int32), ('pad2', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+                   ('stor', C.c_int32), ('xg', C.c_int32), ('og', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
 
 
 class TfnasCellWs(C.Structure):
@@ -51,7 +51,7 @@ class TfnasStage(C.Structure):
 
 
 class TfnasPathDesc(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'nstage', 'soft', 'need_dx0', 'efree_mask_lo', 'pad0')]
+    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'nstage', 'soft', 'need_dx0', 'efree_mask_lo', 'dual')]
                 + [('stage', TfnasStage * MAX_STAGES), ('cell', TfnasCellDesc * MAX_CELLS)])
 
 

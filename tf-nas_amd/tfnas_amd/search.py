@@ -84,7 +84,7 @@ class SearchState:
         self.arena = WeightArena(self.model)
         self.runner = PathRunner(self.model, self.arena, self.storage)
         if len(self._wgrad_streams) == 2:
-            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1]}
+            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
         self._op_params, self._op_span, self._mom_bound = {}, {}, None
         cell_params = set()
         for c in self.model.cells():
@@ -398,7 +398,7 @@ class SearchState:
         self._side_stream = chosen[0]
         self._wgrad_streams = chosen[1:3]
         if self.runner is not None and len(self._wgrad_streams) == 2:
-            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1]}
+            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
 
     # -- host mirror of the log_alphas -------------------------------------------------------------------------
     # The gumbel pass of a w-step needs the sampled candidate indices ON THE HOST (they decide which kernels are
@@ -484,6 +484,9 @@ FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
 OVERLAP_ALLREDUCE = os.environ.get('TFNAS_OVERLAP_ALLREDUCE', '1') != '0'
 # choose the w-step's side streams by measured concurrency (streams.py); 0: first streams torch / the library hand out
 PICK_STREAMS = os.environ.get('TFNAS_PICK_STREAMS', '1') != '0'
+# w-step: both bi-sampling paths as two groups of one path descriptor (one launch per kernel for both); 0: two interleaved paths
+# on two streams (round 2)
+DUAL_PATHS = os.environ.get('TFNAS_DUAL', '1') != '0'
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
@@ -670,7 +673,13 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         state._need_zero_grad = False
     state.begin_weight_grads()
     feat = model._stem(x)
-    if bi_sampling:
+    if bi_sampling and DUAL_PATHS:
+        # both paths through one launch per kernel (TfnasPathDesc.dual), everything on the current stream
+        state.side_stream(dev)                  # (picks the weight-gradient side stream on first use)
+        oa, ob = runner.dual(feat, idx_a, idx_b)
+        logits_g = model.classifier(model._head(oa))
+        loss = F.cross_entropy(logits_g, target) + F.cross_entropy(model.classifier(model._head(ob)), target)
+    elif bi_sampling:
         cur = torch.cuda.current_stream(dev)
         side = state.side_stream(dev)
         oa, ob = runner.bisampled(feat, idx_a, idx_b, side)

@@ -68,5 +68,15 @@ for kind in ('alpha', 'w+w'):
         for s, e, n in ks:
             short[fam(n)][0] += 1
             short[fam(n)][1] += e - s
-        top = sorted(short.items(), key=lambda kv: -kv[1][1])[:8]
+        top = sorted(short.items(), key=lambda kv: -kv[1][1])[:int(__import__('os').environ.get('CHAIN_TOP', '8'))]
         print('      top: ' + ', '.join('%s %dx %.0fus' % (k, v[0] // n_occ, v[1] / n_occ / 1e3) for k, v in top))
+
+# optional: ordered timeline of the LAST w+w segment (all queues) -> file given as third argument
+if len(sys.argv) > 3:
+    ww = [s for s in segs if s[0] == 'w+w']
+    if ww:
+        _, a, b = ww[-1]
+        with open(sys.argv[3], 'w') as f:
+            for s0, e0, n, q in ev:
+                if a <= s0 < b:
+                    f.write('%9.1f %8.1f q%s %s\n' % ((s0 - a) / 1e3, (e0 - s0) / 1e3, q, n.replace('void ', '')[:100]))
