@@ -138,6 +138,20 @@ int tfnas_abi_version(void);
  * same ABI -- with it. */
 int tfnas_has_bf16_storage(void);
 
+/* ---- cross-rank BatchNorm statistics ("sync-stats") -------------------------------------------------------------------------
+ * Data-parallel runs normalise with PER-RANK batch statistics by default (what un-synced DDP / nn.DataParallel do; the
+ * reference's search is effectively single-GPU).  With a hook installed every BatchNorm site uses the
+ * statistics of the GLOBAL batch -- the analogue of apex's convert_syncbn_model in the reference's retrain script
+ * (train_eval_amp.py:155-157) -- forward (sum, sum of squares per channel) and backward (the two BatchNorm-backward sums).
+ * fn(user, table, ndoubles, stream) is called by every launch sequence right after a table of per-channel sums has been
+ * reduced on `stream` and before any consumer of it is enqueued.  It must enqueue, ordered on `stream`, an all-reduce(SUM) of
+ * table[0 .. ndoubles) over the ranks followed by a multiplication by 1 / world: the kernels keep dividing by the LOCAL element
+ * count, so the scaled sums give exactly the global mean / variance / gradient means.  Returns 0 or an error code (propagated).
+ * world: number of ranks (unbiased running-variance correction of the affine path).  fn = NULL: off (the default).
+ * Process-global; E-free mode (statistics from the Gram matrix of x) is refused while a hook is installed. */
+typedef int (*tfnas_stats_sync_fn)(void *user, double *table, uint64_t ndoubles, void *stream);
+int tfnas_set_stats_sync(tfnas_stats_sync_fn fn, void *user, int world);
+
 /* Destroys the library-owned side streams / events (after synchronising them).  Optional; safe to call more than once. */
 int tfnas_shutdown(void);
 
@@ -325,6 +339,8 @@ int tfnas_path_destroy(void *ctx);
  * creates.  HIP maps streams onto a few hardware queues in creation order; a caller that has measured which of its streams
  * really run concurrently (tfnas_amd/streams.py) hands the good ones in here. */
 int tfnas_path_set_side_stream(void *ctx, void *stream);
+/* Optional SECOND weight-gradient stream (caller-owned; NULL: none): the weight-gradient kernels of odd cells go there. */
+int tfnas_path_set_side_stream2(void *ctx, void *stream);
 
 /* Validate + plan every cell (tfnas_cell_plan), chain the geometry (cell i+1's input extent = cell i's output), lay out
  * the arena.  May be called again on the same context with different candidates / widths (every weight step does). */

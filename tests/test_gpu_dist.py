@@ -180,3 +180,112 @@ def test_two_rank_gpu_step_equals_oracle_shardwise_average(tmp_path):
     for a, b in zip(o.arch_parameters(), r0['arch']):
         assert torch.allclose(b, a.detach(), atol=1e-3)
     print('2-rank GPU step vs oracle shard-wise average: worst |dw| %.3g' % worst)
+
+
+def _sync_inputs():
+    import torch
+    g = torch.Generator().manual_seed(4321)
+    X = torch.randn(8, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 100, (8,), generator=g)
+    return X, Y
+
+
+def _search_step_state(X, Y, group_size, rank, sync):
+    """ONE w-step + alpha-step of the seeded supernet on images [rank*B/W, (rank+1)*B/W) of the global batch."""
+    import torch
+    from tfnas_amd import Network, load_lat_lookup, geometry, search, syncbn
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(2)
+    model = Network(100, geometry.initial_mc_num_dddict(), load_lat_lookup('gpu')).to(dev)
+    model.set_temperature(5.0)
+    if sync:
+        assert syncbn.enable()
+    state = search.SearchState(model)
+    opt_w, opt_a = search.make_optimizers(model)
+    noise = search.NoiseSource(7)
+    n = X.shape[0] // group_size
+    xs, ys = X[n * rank:n * (rank + 1)].to(dev), Y[n * rank:n * (rank + 1)].to(dev)
+    search.w_step(state, xs, ys, opt_w, 5.0, noise.exp(dev), noise.rand_pos())
+    after_w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    _, _, lat, grads = search.a_step(state, xs, ys, opt_a, 15.0, 0.1, 5.0, noise.exp(dev), return_grads=True)
+    torch.cuda.synchronize()
+    out = dict(after_w=after_w, arch=[p.detach().cpu().clone() for p in model.arch_parameters()],
+               grads=[t.cpu() for t in grads], lat=float(lat), sync_calls=syncbn.calls())
+    if sync:
+        syncbn.disable()
+    return out
+
+
+def _retrain_step_state(X, Y, group_size, rank, sync, group=None):
+    """Two training steps of a small derived network (affine BatchNorm, running statistics) on this rank's shard."""
+    import torch
+    from collections import OrderedDict
+    from tfnas_amd import geometry as g, model_eval as me, syncbn
+    dev = torch.device('cuda', 0)
+    mc = g.initial_mc_num_dddict()
+    arch = OrderedDict((st, OrderedDict((b, (3 * i + j) % 8) for j, b in enumerate(mc[st]))) for i, st in enumerate(mc))
+    torch.manual_seed(5)
+    model = me.Network(100, arch, mc, None, 0.0, 0.0).to(dev)
+    if sync:
+        assert syncbn.enable()
+    opt = torch.optim.SGD(model.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+    crit = me.CrossEntropyLabelSmooth(100, 0.1)
+    n = X.shape[0] // group_size
+    xs, ys = X[n * rank:n * (rank + 1), :, :96, :96].to(dev), Y[n * rank:n * (rank + 1)].to(dev)
+    for _ in range(2):
+        me.train_step(model, xs, ys, crit, opt, 5.0, group)
+    torch.cuda.synchronize()
+    if sync:
+        syncbn.disable()
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def _sync_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, 'tf-nas_amd'),):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    X, Y = _sync_inputs()
+    res = dict(search=_search_step_state(X, Y, world, rank, True), retrain=_retrain_step_state(X, Y, world, rank, True))
+    torch.save(res, os.path.join(outdir, 's%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_sync_stats_two_ranks_equal_one_rank_at_the_global_batch(tmp_path):
+    """tfnas_amd.syncbn (tfnas_set_stats_sync: every BatchNorm site all-reduces its forward statistics and its backward
+    sums): 2 ranks x 4 images with sync-stats must reproduce ONE process at 8 images -- search step (weights after the w-step,
+    architecture gradients / parameters after the alpha-step) and the derived network's training step incl. the running
+    statistics of its affine BatchNorms -- up to fp32 summation order.  Without the switch the two differ (per-rank statistics)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / ('s%d.pt' % r)) for r in (0, 1))
+    assert r0['search']['sync_calls'] > 100                          # the hook really ran (6 tables per cell and step)
+    X, Y = _sync_inputs()
+    one = _search_step_state(X, Y, 1, 0, False)
+    for k, a in one['after_w'].items():
+        b = r0['search']['after_w'][k]
+        assert torch.equal(b, r1['search']['after_w'][k]), k
+        err, ref = float((b - a).abs().max()), float(a.abs().max())
+        assert err <= 1e-5 + 2e-4 * ref, (k, err, ref)
+    assert abs(one['lat'] - r0['search']['lat']) < 1e-4
+    for a, b in zip(one['grads'], r0['search']['grads']):
+        assert torch.allclose(b, a, atol=2e-5), float((b - a).abs().max())
+    for a, b in zip(one['arch'], r0['search']['arch']):
+        assert torch.allclose(b, a, atol=1e-4)
+    ref = _retrain_step_state(X, Y, 1, 0, False)
+    worst = 0.0
+    for k, a in ref.items():
+        b = r0['retrain'][k]
+        if a.dtype.is_floating_point:
+            err, rf = float((b - a).abs().max()), float(a.abs().max())
+            assert err <= 1e-5 + 5e-4 * rf, (k, err, rf)
+            worst = max(worst, err)
+    print('sync-stats: 2 ranks == 1 rank at the global batch; worst retrain |diff| %.3g' % worst)

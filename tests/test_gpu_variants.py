@@ -96,6 +96,21 @@ def test_streaming_depthwise_equals_tiled_and_side_stream_is_bit_identical(tmp_p
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
 
 
+def test_wave_level_tn_weight_gradients_equal_the_lds_tiled_kernels(tmp_path):
+    """csrc/wgrad_tn.hip (TFNAS_WGRAD_TN=2: the 1x1 weight gradients as wave-level TN GEMMs without LDS staging, every cell;
+    off by default) vs the LDS-tiled split-K kernels: same products, other summation order."""
+    base = _run_child(tmp_path, 'base', {'TFNAS_WGRAD_TN': '0'})
+    tn = _run_child(tmp_path, 'tn', {'TFNAS_WGRAD_TN': '2'})
+    assert base.keys() == tn.keys() and len(base) > 20
+    ngrad = 0
+    for k in base:
+        a, b = tn[k].double(), base[k].double()
+        tol = 2e-5 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+        ngrad += '/g' in k
+    assert ngrad >= 30                                            # weight gradients of the sampled launches were compared
+
+
 def test_fused_se_excite_equals_gemm_path(tmp_path):
     """Per-image fused excite kernels (default) vs the MFMA GEMM formulation (TFNAS_SE_GEMM=1): other summation order."""
     base = _run_child(tmp_path, 'base', {})

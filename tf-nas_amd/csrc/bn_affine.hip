@@ -74,7 +74,8 @@ int launch_bn_fwd_fix(double* stats, int nch, uint64_t cnt, float eps, const flo
                       float* rvar, float momentum, int eval, hipStream_t s) {
     if (nch <= 0) return 0;
     ProfScope _prof(TK_SMALL, s);
-    const double unbias = cnt > 1 ? (double)cnt / (double)(cnt - 1) : 1.0;
+    const uint64_t gcnt = cnt * stats_world();          // sync-stats: the statistics are those of the global batch
+    const double unbias = gcnt > 1 ? (double)gcnt / (double)(gcnt - 1) : 1.0;
     hipLaunchKernelGGL(k_bn_fwd_fix, dim3(cdiv(nch, 256)), dim3(256), 0, s, stats, nch, 1.0 / (double)cnt, unbias, eps, gamma,
                        beta, rmean, rvar, momentum, eval);
     return (int)hipGetLastError();

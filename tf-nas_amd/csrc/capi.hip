@@ -95,6 +95,16 @@ extern "C" int tfnas_shutdown(void) {
     return 0;
 }
 
+StatsSync g_stats_sync = {nullptr, nullptr, 1};
+
+extern "C" int tfnas_set_stats_sync(tfnas_stats_sync_fn fn, void* user, int world) {
+    if (fn && world < 1) return TFNAS_ERANGE;
+    g_stats_sync.fn = fn;
+    g_stats_sync.user = user;
+    g_stats_sync.world = fn ? world : 1;
+    return 0;
+}
+
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
 extern "C" int tfnas_has_bf16_storage(void) {
@@ -250,7 +260,7 @@ static int bn_fwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     uint64_t cnt;
     bn_site(d, site, nch, cnt);
     return launch_bn_fwd_fix(stats, nch, cnt, d.eps, bn->weight[site], bn->bias[site], bn->running_mean[site],
-                             bn->running_var[site], bn->momentum, bn->eval, s);
+                             bn->running_var[site], bn->momentum, bn->eval, s);     // (sync-stats: kernels.h stats_world)
 }
 
 int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s) {
@@ -268,12 +278,16 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
     const TfnasCellDesc& d = dc;
     if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));          // 1x1 expand (all groups) + BN1 statistics
     else TRY(launch_expand_stats_gram(d, b.x, stats1, b.part, s));            // E-free: BN1 statistics from the Gram matrix of x
+    const bool sync = !(bn && bn->eval);          // (eval mode normalises with the running statistics: nothing to reduce)
+    if (sync) TRY(stats_sync(stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
     if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
     TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));          // BN1+act fused load, depthwise, BN2 statistics
+    if (sync) TRY(stats_sync(stats2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));
     TRY(launch_se_pool(d, b.D, stats2, pooled, s));                           // SE squeeze (SE groups only)
     TRY(launch_se_fc_fwd(d, pooled, hpre, gate, b.part, TFNAS_PART_FLOATS, s));    // SE excite (K-split partials in `part`)
     TRY(launch_project_fwd(d, b.D, gate, stats2, b.Pr, stats3, b.part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
+    if (sync) TRY(stats_sync(stats3, 2 * (size_t)d.G * d.oc, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 2, stats3, s));
     if (b.drop_scale && d.has_res) {
         // drop-connect (tools/utils.py:77-86): out = scale[n] * BN3(.) + x -- the mix kernel without its residual, then one pass
@@ -341,6 +355,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         }
     }
     TRY(launch_mix_bwd_stats(d, b.dout, b.Pr, stats3, b.x, red3, part, s));           // BN3 backward sums (+ d wmix)
+    TRY(stats_sync(red3, 2 * (size_t)d.G * d.oc, s));
     if (b.dwmix) TRY(launch_mix_dw(d, red3, b.red + ws.off_resdot, b.dwmix, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 2, red3, s));
     // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
@@ -357,6 +372,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)ws.dEh, s));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
+    TRY(stats_sync(red2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 1, red2, s));
     if (d.need_wgrad) {
         // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
@@ -366,10 +382,11 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
-    if (bn) {
-        // (unfused: the reduction that also builds cb1 would use the sums before the affine fix)
+    if (bn || stats_sync_on()) {
+        // (unfused: the reduction that also builds cb1 would use the sums before the affine fix / the cross-rank reduction)
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, nullptr));
-        TRY(bn_bwd_fix(d0, bn, 0, red1, s));
+        TRY(stats_sync(red1, 2 * (size_t)d.M, s));
+        if (bn) TRY(bn_bwd_fix(d0, bn, 0, red1, s));
         TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     } else {
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
@@ -477,6 +494,7 @@ extern "C" int tfnas_head_affine_fwd(const TfnasCellDesc* dp, const TfnasBnAffin
     TfnasCellDesc d = d0;
     d.eps = -1.f;
     TRY(launch_expand_fwd(d, x, E, stats, part, s));
+    TRY(stats_sync(stats, 2 * (size_t)d.M, s));
     TRY(launch_bn_fwd_fix(stats, d0.g[0].mc, (uint64_t)d0.N * d0.H * d0.W, d0.eps, bn->weight[0], bn->bias[0],
                           bn->running_mean[0], bn->running_var[0], bn->momentum, bn->eval, s));
     TRY(launch_head_pool(d, E, stats, pooled, s));
@@ -495,6 +513,7 @@ extern "C" int tfnas_head_affine_bwd(const TfnasCellDesc* dp, const TfnasBnAffin
     d.eps = -1.f;
     const uint64_t cnt = (uint64_t)d0.N * d0.H * d0.W;
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));
+    TRY(stats_sync(red, 2 * (size_t)d.M, s));
     TRY(launch_bn_bwd_fix(red, d0.g[0].mc, cnt, bn->weight[0], bn->bias[0], bn->g_weight[0], bn->g_bias[0], s));
     if (bn->eval) HIP_TRY(hipMemsetAsync(red, 0, sizeof(double) * 2 * (size_t)d0.g[0].mc, s));
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
@@ -512,6 +531,7 @@ extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E,
     if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
     hipStream_t s = S(stream);
     TRY(launch_expand_fwd(d, x, E, stats, part, s));          // 1x1 conv 320->1280 + BN statistics
+    TRY(stats_sync(stats, 2 * (size_t)d.M, s));
     TRY(launch_head_pool(d, E, stats, pooled, s));            // BN + swish + global average pool
     return 0;
 }
@@ -525,6 +545,7 @@ extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const flo
     if (d.need_wgrad && !d.g[0].g_expand) return TFNAS_ENULL;
     hipStream_t s = S(stream);
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));       // pool + swish backward, BN-backward sums
+    TRY(stats_sync(red, 2 * (size_t)d.M, s));
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
     float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
     TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));

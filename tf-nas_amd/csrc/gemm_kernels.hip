@@ -1073,6 +1073,10 @@ static size_t spread_lds(size_t shm, long wgs) {
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s) {
+    {
+        int rc = 0;
+        if (launch_project_wgrad_tn(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part, s, &rc)) return rc;
+    }
     ProfScope _prof(TK_PROJECT_WGRAD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     const int Po = d.N * d.Ho * d.Wo;
@@ -1173,6 +1177,10 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
 
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s) {
+    {
+        int rc = 0;
+        if (launch_expand_wgrad_tn(d, dEh, E, cb1, x, part, s, &rc)) return rc;
+    }
     ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;

@@ -4,6 +4,19 @@
 #include <hip/hip_runtime.h>
 #include "tfnas_hip.h"
 
+// cross-rank BatchNorm statistics hook (tfnas_set_stats_sync, capi.hip)
+struct StatsSync {
+    tfnas_stats_sync_fn fn;
+    void* user;
+    int world;
+};
+extern StatsSync g_stats_sync;
+static inline bool stats_sync_on() { return g_stats_sync.fn != nullptr; }
+static inline int stats_sync(double* table, size_t ndoubles, hipStream_t s) {
+    return g_stats_sync.fn ? g_stats_sync.fn(g_stats_sync.user, table, (uint64_t)ndoubles, (void*)s) : 0;
+}
+static inline uint64_t stats_world() { return (g_stats_sync.fn && g_stats_sync.world > 1) ? (uint64_t)g_stats_sync.world : 1; }
+
 // gemm_kernels.hip
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
                       hipStream_t s);
@@ -23,6 +36,13 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
 int expand_dgrad_splits(const TfnasCellDesc& d);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s);
+
+// wgrad_tn.hip: wave-level TN GEMMs (no LDS staging) for the two 1x1 weight gradients; return false when not applicable
+bool launch_project_wgrad_tn(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D, const float* gate,
+                             const double* stats2, const double* stats3, const double* red3, const float* wmix, float* part,
+                             hipStream_t s, int* rc);
+bool launch_expand_wgrad_tn(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1, const float* x,
+                            float* part, hipStream_t s, int* rc);
 
 // dwconv_kernels.hip
 // E == nullptr: E-free mode (efree.h) -- the expanded activation is recomputed from x inside the depthwise kernels

@@ -44,6 +44,7 @@ struct PathCtx {
     uint64_t ring[NRING], dxp;
     TfnasPathWs ws;
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;       // optional second weight-gradient stream (caller-supplied): odd cells go there
     bool own_side = true;              // false: the caller supplied the side stream (tfnas_path_set_side_stream)
     hipEvent_t fork[TFNAS_MAX_CELLS][3];
     hipEvent_t wdone[TFNAS_MAX_CELLS];
@@ -296,6 +297,16 @@ extern "C" int tfnas_path_set_side_stream(void* ctx, void* stream) {
     return 0;
 }
 
+// A second weight-gradient stream: the weight-gradient kernels of odd cells go there.  In the dual mode the data-gradient
+// chain of both bi-sampling paths is ONE queue and the weight-gradient kernels (leaves of the dependency graph, a third of
+// the step's kernel time) are what bounds the backward; two queues of them overlap their launch latencies.
+extern "C" int tfnas_path_set_side_stream2(void* ctx, void* stream) {
+    PathCtx* c = static_cast<PathCtx*>(ctx);
+    if (!c) return TFNAS_ENULL;
+    c->side2 = S(stream);
+    return 0;
+}
+
 extern "C" int tfnas_path_plan(void* ctx, const TfnasPathDesc* pd, TfnasPathWs* ws) {
     if (!ctx || !pd) return TFNAS_ENULL;
     return plan_path(*static_cast<PathCtx*>(ctx), *pd, ws);
@@ -426,11 +437,11 @@ int bwd_cell(BwdRun& r, int i) {
     CellSide so = {};
     const bool side = r.side_on && pd.cell[i].need_wgrad;
     if (side) {
-        so.side = c.side;
+        so.side = (c.side2 && (i & 1)) ? c.side2 : c.side;
         for (int k = 0; k < 3; ++k) so.fork[k] = c.fork[i][k];
     }
     TRY(cell_bwd_impl(pd.cell[i], c.cws[i], b, r.s, side ? &so : nullptr));
-    if (side) HIP_TRY(hipEventRecord(c.wdone[i], c.side));
+    if (side) HIP_TRY(hipEventRecord(c.wdone[i], so.side));
     return 0;
 }
 
@@ -489,8 +500,13 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         if (!r.side_on) continue;
         hipError_t e = hipEventRecord(r.c->join, r.c->side);
         if (e == hipSuccess) e = hipStreamWaitEvent(r.s, r.c->join, 0);
+        if (e == hipSuccess && r.c->side2) {
+            e = hipEventRecord(r.c->xfork, r.c->side2);
+            if (e == hipSuccess) e = hipStreamWaitEvent(r.s, r.c->xfork, 0);
+        }
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(r.c->side);
+            if (r.c->side2) (void)hipStreamSynchronize(r.c->side2);
             if (rc == 0) rc = (int)e;
         }
     }

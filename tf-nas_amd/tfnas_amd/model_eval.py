@@ -189,15 +189,100 @@ class CrossEntropyLabelSmooth(nn.Module):
         return F.cross_entropy(xs, targets, label_smoothing=self.epsilon)
 
 
-def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None):
+class RetrainState:
+    """Flat weight / gradient / momentum arenas of the derived network (path.WeightArena) + the fused step tail of the search
+    path: ``.grad`` of every parameter is a view into ONE gradient buffer (autograd accumulates in place), so a data-parallel
+    step is ONE all-reduce of that buffer (no ``torch.cat``, no copy back -- what apex DDP's ``delay_allreduce`` flattening does,
+    train_eval_amp.py:188) and clip_grad_norm_ + SGD(momentum, weight decay) are the two launches of ``tfnas_sgd_clip_step``
+    (1 / world folded in), sharing the momentum buffers with the caller's ``torch.optim.SGD`` (checkpoints keep working)."""
+
+    def __init__(self, model):
+        from .path import WeightArena
+        self.model = model
+        self.arena = WeightArena(model)
+        self._bound = None
+        self._scratch = self._gnorm = None
+
+    def intact(self):
+        return self.arena.intact()
+
+    @staticmethod
+    def fusable(opt):
+        g = opt.param_groups
+        return (isinstance(opt, torch.optim.SGD) and len(g) == 1 and not g[0].get('nesterov') and not g[0].get('dampening')
+                and not g[0].get('maximize'))
+
+    def _bind_momentum(self, opt):
+        a = self.arena
+        probe = a.params[0]
+        buf = opt.state.get(probe, {}).get('momentum_buffer')
+        if self._bound is opt and buf is not None and buf.data_ptr() == a.m.data_ptr() + 4 * a.slot[id(probe)][0]:
+            return
+        with torch.no_grad():
+            for p in a.params:
+                o, n = a.slot[id(p)]
+                view = a.m[o:o + n].view(p.shape)
+                old = opt.state.get(p, {}).get('momentum_buffer')
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old)
+                elif old is None:
+                    view.zero_()
+                opt.state[p]['momentum_buffer'] = view
+        self._bound = opt
+
+    def begin(self):
+        """Zero the gradient arena (one memset) and make every .grad a view of it."""
+        a = self.arena
+        a.g.zero_()
+        for p in a.params:
+            if p.grad is None or p.grad.data_ptr() != a.grad_ptr(p):
+                p.grad = a.grad_view(p)
+
+    def step(self, opt, grad_clip, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        a = self.arena
+        self._bind_momentum(opt)
+        hp = opt.param_groups[0]
+        scale = 1.0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(a.g, group=group)            # ONE message: the whole gradient arena
+            scale = 1.0 / dist.get_world_size(group)
+        dev = a.device
+        nblk = (a.total + 8191) // 8192
+        if self._scratch is None or self._scratch.numel() < nblk + 8:
+            self._scratch = torch.empty(max(4096, 2 * nblk), device=dev, dtype=torch.float64)
+            self._gnorm = torch.zeros(2, device=dev, dtype=torch.float32)
+        off, ln = (C.c_uint64 * 1)(0), (C.c_uint64 * 1)(a.total)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().tfnas_sgd_clip_step(_lib.ptr(a.w), _lib.ptr(a.g), _lib.ptr(a.m), 1, off, None, ln, float(grad_clip),
+                                                  float(hp['lr']), float(hp['momentum']), float(hp['weight_decay']), float(scale),
+                                                  _lib.ptr(self._scratch), self._scratch.numel(), _lib.ptr(self._gnorm), stream),
+                   'tfnas_sgd_clip_step')
+
+
+def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None, fused=True):
     """One iteration of train_eval.py:228-252 (forward, label-smoothed loss, backward, clip, SGD); with a process group the
-    gradients are averaged with one flat all-reduce before clipping (one process per GPU instead of apex DDP)."""
+    gradients are averaged with ONE all-reduce of the flat gradient arena before clipping (one process per GPU instead of apex
+    DDP).  ``fused`` (GPU models with a plain torch.optim.SGD): RetrainState -- gradient arena + tfnas_sgd_clip_step; otherwise
+    torch's clip_grad_norm_ + optimizer.step()."""
     import torch.distributed as dist
     model.train()
+    st = None
+    if fused and x.is_cuda and RetrainState.fusable(optimizer):
+        st = getattr(model, '_retrain_state', None)
+        if st is None or not st.intact():
+            st = RetrainState(model)
+            object.__setattr__(model, '_retrain_state', st)         # (not a submodule / buffer: stays out of state_dict)
+        st.begin()
     logits = model(x)
     loss = criterion(logits, target)
-    optimizer.zero_grad()
+    if st is None:
+        optimizer.zero_grad()
     loss.backward()
+    if st is not None:
+        st.step(optimizer, grad_clip, group)
+        return loss.detach(), logits.detach()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         grads = [p.grad for p in model.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])

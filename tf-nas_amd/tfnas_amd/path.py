@@ -190,6 +190,10 @@ class PathRunner:
         if ws is not None and getattr(s, 'side', None) is not ws:
             check(self.lib.tfnas_path_set_side_stream(s.ctx, C.c_void_p(ws.cuda_stream)), 'tfnas_path_set_side_stream')
             s.side = ws
+        ws2 = self.wgrad_streams.get(name + '2')
+        if ws2 is not None and getattr(s, 'side2', None) is not ws2:
+            check(self.lib.tfnas_path_set_side_stream2(s.ctx, C.c_void_p(ws2.cuda_stream)), 'tfnas_path_set_side_stream2')
+            s.side2 = ws2
         return s
 
     def _plan(self, name, idxs, x0h, need_wgrad, need_dx0, need_dbetas):

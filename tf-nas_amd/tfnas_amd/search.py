@@ -84,7 +84,7 @@ class SearchState:
         self.arena = WeightArena(self.model)
         self.runner = PathRunner(self.model, self.arena, self.storage)
         if len(self._wgrad_streams) == 2:
-            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
+            self.runner.wgrad_streams = self._wgrad_map()
         self._op_params, self._op_span, self._mom_bound = {}, {}, None
         cell_params = set()
         for c in self.model.cells():
@@ -386,6 +386,12 @@ class SearchState:
             self._pick_streams(device)
         return self._side_stream
 
+    def _wgrad_map(self):
+        m = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
+        if DUAL_WGRAD_STREAMS >= 2:
+            m['AB2'] = self._wgrad_streams[1]       # dual mode: odd cells' weight-gradient kernels on a second queue
+        return m
+
     def _pick_streams(self, device):
         """The three extra streams of a w-step -- path B and the two weight-gradient streams -- are chosen by MEASURED
         concurrency with the current stream and with each other (streams.py): HIP's stream -> hardware-queue mapping
@@ -398,7 +404,7 @@ class SearchState:
         self._side_stream = chosen[0]
         self._wgrad_streams = chosen[1:3]
         if self.runner is not None and len(self._wgrad_streams) == 2:
-            self.runner.wgrad_streams = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
+            self.runner.wgrad_streams = self._wgrad_map()
 
     # -- host mirror of the log_alphas -------------------------------------------------------------------------
     # The gumbel pass of a w-step needs the sampled candidate indices ON THE HOST (they decide which kernels are
@@ -484,9 +490,14 @@ FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
 OVERLAP_ALLREDUCE = os.environ.get('TFNAS_OVERLAP_ALLREDUCE', '1') != '0'
 # choose the w-step's side streams by measured concurrency (streams.py); 0: first streams torch / the library hand out
 PICK_STREAMS = os.environ.get('TFNAS_PICK_STREAMS', '1') != '0'
-# w-step: both bi-sampling paths as two groups of one path descriptor (one launch per kernel for both); 0: two interleaved paths
-# on two streams (round 2)
-DUAL_PATHS = os.environ.get('TFNAS_DUAL', '1') != '0'
+# w-step: 1 = both bi-sampling paths as two groups of ONE path descriptor (TfnasPathDesc.dual: one launch per kernel for both
+# paths, one dependency chain + the weight-gradient queue(s)); 0 (default) = two interleaved paths on two streams + two
+# weight-gradient streams (round 2).  Measured at B = 128 on one MI355X: the dual mode cuts the summed
+# kernel time of a pair from 147 to 103 ms and the launches of a w-step from ~1500 to ~1000, but the step gets LONGER (20.3 vs
+# 19.1 ms): it is bound by the length of ONE chain of ~1000 dependent launches + the weight-gradient queue, and with the two
+# paths merged nothing overlaps that chain's per-launch latencies any more.
+DUAL_PATHS = os.environ.get('TFNAS_DUAL', '0') == '1'
+DUAL_WGRAD_STREAMS = int(os.environ.get('TFNAS_DUAL_WGRAD_STREAMS', '2'))     # weight-gradient queues of the dual mode (1 or 2)
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)

@@ -1,0 +1,83 @@
+"""Cross-rank BatchNorm statistics ("sync-stats") for data-parallel runs of the HIP path.
+
+By default every rank normalises with the statistics of ITS shard of the batch (what un-synced DDP / nn.DataParallel do; the
+reference's search is effectively single-GPU).  ``enable(group)`` installs a hook in the HIP library
+(include/tfnas_hip.h: tfnas_set_stats_sync) that all-reduces every per-channel (sum, sum of squares) table of the forward and
+every BatchNorm-backward sum table of the backward over the ranks, so all BatchNorm sites -- search cells, stems, head, and the
+derived network's affine BatchNorms -- use the statistics of the GLOBAL batch: an N-rank run is then the single-GPU run at N
+times the batch.  The reference's analogue is apex's ``convert_syncbn_model`` in the retrain script (train_eval_amp.py:155-157).
+
+Cost: 6 small all-reduces per cell and direction pair (<= 2 x 1536 doubles each) on the step's critical path -- an opt-in mode,
+not the throughput default.  E-free mode is switched off by the library while the hook is installed.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_STATE = {'cb': None, 'group': None, 'world': 1, 'calls': 0}
+_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class _Raw:
+    """Zero-copy view of device memory the library owns (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2}
+
+
+def _libs():
+    out = [_lib.lib()]
+    try:
+        out.append(_lib.lib(True))
+    except Exception:
+        pass
+    return out
+
+
+def enable(group=None):
+    """Install the hook for ``group`` (default: WORLD).  No-op without an initialised process group or at world size 1
+    unless tfnas_amd.search.FORCE_ALLREDUCE_AT_WORLD_1 is set (tests)."""
+    import torch.distributed as dist
+    from . import search
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    world = dist.get_world_size(group)
+    if world == 1 and not search.FORCE_ALLREDUCE_AT_WORLD_1:
+        return False
+    inv = 1.0 / world
+
+    def hook(_user, table, n, stream):
+        try:
+            dev = torch.device('cuda', torch.cuda.current_device())
+            ext = torch.cuda.ExternalStream(int(stream) if stream else 0, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_Raw(table, n), device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                if world > 1:
+                    t.mul_(inv)
+            _STATE['calls'] += 1
+            return 0
+        except Exception as e:                      # (an exception must not unwind through the C frames)
+            _STATE['error'] = e
+            return -1000
+    cb = _FN(hook)
+    for l in _libs():
+        _lib.check(l.tfnas_set_stats_sync(C.cast(cb, C.c_void_p), None, int(world)), 'tfnas_set_stats_sync')
+    _STATE.update(cb=cb, group=group, world=world)     # (keeps the ctypes thunk alive)
+    return True
+
+
+def disable():
+    for l in _libs():
+        l.tfnas_set_stats_sync(None, None, 1)
+    _STATE.update(cb=None, group=None, world=1)
+
+
+def enabled():
+    return _STATE['cb'] is not None
+
+
+def calls():
+    return _STATE['calls']
