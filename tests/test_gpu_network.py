@@ -264,8 +264,13 @@ def test_width_sweep_matches_oracle(lut, widths):
     from tfnas_amd.functions import MixedOpFn
     for p in o.weight_parameters() + m.weight_parameters():
         p.requires_grad = True
+    from tfnas_amd import model_search as ms
+    old_mp, ms.MODULE_PATHS = ms.MODULE_PATHS, False      # per-cell route: one MixedOpFn per cell, whose saved tensors we read
     MixedOpFn.fwd_sink = []
-    sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    try:
+        sm, _ = m(x.cuda(), True, 'gumbel', exp_noise=noise.cuda())
+    finally:
+        ms.MODULE_PATHS = old_mp
     torch.cuda.synchronize()
     recs, MixedOpFn.fwd_sink = MixedOpFn.fwd_sink, None
     masks = []

@@ -111,15 +111,23 @@ def test_wave_level_tn_weight_gradients_equal_the_lds_tiled_kernels(tmp_path):
     assert ngrad >= 30                                            # weight gradients of the sampled launches were compared
 
 
-def test_fused_se_excite_equals_gemm_path(tmp_path):
-    """Per-image fused excite kernels (default) vs the MFMA GEMM formulation (TFNAS_SE_GEMM=1): other summation order."""
+def test_se_excite_variants_agree(tmp_path):
+    """Three formulations of the squeeze-excite FCs: wave-level MFMA kernels without LDS staging (default where every SE
+    group's width is a multiple of 4), per-image fused kernels (TFNAS_SE_WAVE=0) and LDS-tiled MFMA GEMMs (+ TFNAS_SE_GEMM=1):
+    other summation orders only.  (The odd-shape cells of the child have ragged widths: they take the fused / GEMM path in all
+    three runs; the real-geometry cells switch.)"""
     base = _run_child(tmp_path, 'base', {})
-    gemm = _run_child(tmp_path, 'segemm', {'TFNAS_SE_GEMM': '1'})
-    assert base.keys() == gemm.keys() and len(base) > 20
+    fused = _run_child(tmp_path, 'sefused', {'TFNAS_SE_WAVE': '0'})
+    gemm = _run_child(tmp_path, 'segemm', {'TFNAS_SE_WAVE': '0', 'TFNAS_SE_GEMM': '1'})
+    assert base.keys() == gemm.keys() == fused.keys() and len(base) > 20
+    differs = 0
     for k in base:
-        a, b = base[k].double(), gemm[k].double()
-        tol = 5e-5 * float(b.abs().max()) + 1e-6
-        assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+        for other in (fused, gemm):
+            a, b = base[k].double(), other[k].double()
+            tol = 5e-5 * float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+        differs += int(not torch.equal(base[k], fused[k]))
+    assert differs > 0                                            # the switch really selected other kernels
 
 
 def test_arch_project_matches_torch_log_softmax():

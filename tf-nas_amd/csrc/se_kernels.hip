@@ -435,6 +435,171 @@ __global__ __launch_bounds__(256) void k_se_fused_bwd(TfnasCellDesc d, const flo
     }
 }
 
+
+// ============================================================================ wave-level excite GEMMs (no LDS staging)
+// The excite stage is N x mc x se MACs per group -- 10^8 flops -- but as LDS-tiled GEMMs every launch walks 6..72 K-chunks of
+// (load -> LDS -> barrier -> MFMA) back to back with one workgroup per CU: 12-57 us per launch, 50-80 us per cell and
+// direction on the dependency chain of every cell with wide candidates (and 30-40 us for the per-image fused kernels, which
+// re-read both weight matrices once per IMAGE).  Here the operands go from global memory straight into MFMA lanes:
+//   NT (MODE 0 / 1): both operands K-contiguous.  Lane (i = lane % 16, q = lane / 16) loads A[row i][k0 + 4q .. +3] and
+//       B[col i][k0 + 4q .. +3]; MFMA step t takes component t of both, i.e. K slot q of step t carries k = k0 + 4q + t
+//       (a sum over k does not care about the order): 2 loads per 4 MFMAs, a 16 x 16 tile per wave.
+//   NN (MODE 2 / 3): A K-contiguous as above, B[k][col] column-contiguous: for step t the lane loads the float4
+//       B[k0 + 4q + t][col0 + 4i .. +3] whose components are four column tiles with columns 4i + comp: a 16 x 64 tile per wave.
+// All loads of a batch of K-steps are issued before its MFMAs; long K (MODE 0 / 2: K = mid channels) is split over the four
+// waves of a workgroup and summed through LDS in a fixed order.  Requires mc % 4 == 0 for every SE group (aligned float4 rows
+// of W_r; ragged widths keep the GEMM path).  Weights are read once per 16 images instead of once per image.
+#define SEW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int MODE, int ACT>      // MODE 0: hpre = pooled W_r^T + b_r (K = mc, split over the waves);  MODE 1: gate (K = se)
+__global__ __launch_bounds__(256) void k_se_nt(TfnasCellDesc d, SeArgs a) {
+    __shared__ f32x4 red[4][64];
+    const int g = se_group_idx(d, blockIdx.z);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int N = d.N, M = d.M, SE = d.SE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int K = MODE == 0 ? mc : se, ncol = MODE == 0 ? se : mcp;
+    const int j0 = MODE == 0 ? (int)blockIdx.y * 16 : (int)blockIdx.y * 64 + 16 * wave;
+    if ((MODE == 0 ? j0 : (int)blockIdx.y * 64) >= ncol) return;          // (workgroup-uniform)
+    const bool wave_on = j0 < ncol;
+    const int rowA = min(n0 + lj, N - 1);
+    const int rowB = min(j0 + lj, (MODE == 0 ? se : mc) - 1);
+    const float* __restrict__ pa = MODE == 0 ? a.pooled + (size_t)rowA * M + off : a.hpre + (size_t)rowA * SE + so;
+    const float* __restrict__ pb = MODE == 0 ? d.g[g].w_se_r + (size_t)rowB * mc : d.g[g].w_se_e + (size_t)rowB * se;
+    const int nsteps = (K + 15) >> 4;
+    const int first = MODE == 0 ? wave : 0, stride = MODE == 0 ? 4 : 1;
+    f32x4 acc = zero4();
+    constexpr int UB = 6;                                                    // K-steps per batch of loads
+    for (int s0 = first; wave_on && s0 < nsteps; s0 += UB * stride) {
+        f32x4 av[UB], bv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = 16 * (s0 + u * stride) + 4 * lk, kc = min(k, K - 4);
+            av[u] = ld4(pa + kc);
+            bv[u] = ld4(pb + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = 16 * (s0 + u * stride) + 4 * lk;
+            f32x4 x = av[u];
+            if (MODE == 1) x = act_f4<ACT>(x);
+            const f32x4 y = (k < K) ? bv[u] : zero4();                      // (K % 4 == 0: a quad is inside or outside)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = SEW_MFMA(x[t], y[t], acc);
+        }
+    }
+    if (MODE == 0) {
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    } else if (!wave_on) {
+        return;
+    }
+    const int j = j0 + lj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * lk + r;
+        if (n >= N || j >= ncol) continue;
+        if (MODE == 0) a.out0[(size_t)n * SE + so + j] = acc[r] + d.g[g].b_se_r[j];
+        else a.out0[(size_t)n * M + off + j] = j < mc ? sigmoid_f(acc[r] + d.g[g].b_se_e[j]) : 0.f;
+    }
+}
+
+template <int MODE, int ACT>      // MODE 2: dhpre = (dgl W_e) * act'(hpre) (K = mc, split over the waves);  MODE 3: dpooled = dhpre W_r
+__global__ __launch_bounds__(256) void k_se_nn(TfnasCellDesc d, SeArgs a) {
+    __shared__ f32x4 red[MODE == 2 ? 4 : 1][4][64];
+    const int g = se_group_idx(d, blockIdx.z);
+    if (g < 0) return;
+    const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off, se = d.g[g].se, so = d.g[g].se_off;
+    const int N = d.N, M = d.M, SE = d.SE;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lj = lane & 15, lk = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int K = MODE == 2 ? mc : se, ncol = MODE == 2 ? se : mcp, ldb = MODE == 2 ? se : mc;
+    const int c0 = MODE == 2 ? (int)blockIdx.y * 64 : (int)blockIdx.y * 256 + 64 * wave;
+    if ((MODE == 2 ? c0 : (int)blockIdx.y * 256) >= ncol) return;
+    const bool wave_on = c0 < ncol;
+    const int rowA = min(n0 + lj, N - 1);
+    const int colB = min(c0 + 4 * lj, ldb - 4);                             // (ldb % 4 == 0)
+    const float* __restrict__ wB = MODE == 2 ? d.g[g].w_se_e : d.g[g].w_se_r;
+    const int nsteps = (K + 15) >> 4;
+    const int first = MODE == 2 ? wave : 0, stride = MODE == 2 ? 4 : 1;
+    f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+    constexpr int UB = 3;
+    for (int s0 = first; wave_on && s0 < nsteps; s0 += UB * stride) {
+        f32x4 av[UB], gv[UB], bv[UB][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = 16 * (s0 + u * stride) + 4 * lk, kc = min(k, K - 4);
+            if (MODE == 2) {
+                av[u] = ld4(a.dgate + (size_t)rowA * M + off + kc);
+                gv[u] = ld4(a.gate + (size_t)rowA * M + off + kc);
+            } else {
+                av[u] = ld4(a.dhpre + (size_t)rowA * SE + so + kc);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[u][t] = ld4(wB + (size_t)min(k + t, K - 1) * ldb + colB);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = 16 * (s0 + u * stride) + 4 * lk;
+            f32x4 x = av[u];
+            if (MODE == 2) x = x * gv[u] * (splat4(1.f) - gv[u]);
+            x = (k < K) ? x : zero4();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) acc[cp] = SEW_MFMA(x[t], bv[u][t][cp], acc[cp]);
+        }
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) red[wave][cp][lane] = acc[cp];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) acc[cp] = (red[0][cp][lane] + red[1][cp][lane]) + (red[2][cp][lane] + red[3][cp][lane]);
+    } else if (!wave_on) {
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * lk + r;
+        if (n >= N) continue;
+        const int col = c0 + 4 * lj;                                         // four consecutive columns: one 16-byte store
+        if (col >= ncol) continue;
+        f32x4 q = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        if (MODE == 2) {
+            const f32x4 h = ld4(a.hpre + (size_t)n * SE + so + col);
+            q = q * act_d4<ACT>(h);
+            st4(a.out0 + (size_t)n * SE + so + col, q);
+        } else {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp)
+                if (col + cp >= mc) q[cp] = 0.f;
+            st4(a.out0 + (size_t)n * M + off + col, q);
+        }
+    }
+}
+
+// the wave-level kernels need aligned float4 rows of W_r / the gradients: every SE group's mid width a multiple of 4
+static bool se_wave_ok(const TfnasCellDesc& d) {
+    static const int on = [] { const char* e = getenv("TFNAS_SE_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on) return false;
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].se > 0 && ((d.g[g].mc & 3) || (d.g[g].se & 3) || d.g[g].mc < 4)) return false;
+    return true;
+}
+#define SEW_LAUNCH(KERNEL, MODE_, GRID)                                                                   \
+    {                                                                                                    \
+        if (d.act == TFNAS_ACT_RELU)                                                                     \
+            hipLaunchKernelGGL((KERNEL<MODE_, TFNAS_ACT_RELU>), GRID, dim3(256), 0, s, d, a);            \
+        else                                                                                             \
+            hipLaunchKernelGGL((KERNEL<MODE_, TFNAS_ACT_SWISH>), GRID, dim3(256), 0, s, d, a);           \
+    }
+
 // ============================================================================ host launchers
 static int se_count(const TfnasCellDesc& d, int& mcp_max, int& se_max) {
     int t = 0;
@@ -491,6 +656,13 @@ int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, f
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
+    if (se_wave_ok(d)) {
+        SeArgs a = {pooled, gate, hpre, nullptr, nullptr, hpre, nullptr, 1};
+        SEW_LAUNCH(k_se_nt, 0, dim3(cdiv(d.N, 16), cdiv(se_max, 16), ng))
+        a.out0 = gate;
+        SEW_LAUNCH(k_se_nt, 1, dim3(cdiv(d.N, 16), cdiv(mcp_max, 64), ng))
+        return (int)hipGetLastError();
+    }
     if (se_fused_ok(mcp_max, se_max)) {
         const size_t shm = se_fused_lds(mcp_max, se_max);
         if (d.act == TFNAS_ACT_RELU)
@@ -514,6 +686,13 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
     int mcp_max, se_max;
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
+    if (se_wave_ok(d)) {
+        SeArgs a = {nullptr, gate, hpre, dgate, dhpre, dhpre, nullptr, 1};
+        SEW_LAUNCH(k_se_nn, 2, dim3(cdiv(d.N, 16), cdiv(se_max, 64), ng))
+        a.out0 = dpooled;
+        SEW_LAUNCH(k_se_nn, 3, dim3(cdiv(d.N, 16), cdiv(mcp_max, 256), ng))
+        return (int)hipGetLastError();
+    }
     if (se_fused_ok(mcp_max, se_max)) {
         const size_t shm = se_fused_lds(mcp_max, se_max);
         if (d.act == TFNAS_ACT_RELU)
@@ -539,6 +718,8 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gat
     const int ng = se_count(d, mcp_max, se_max);
     if (!ng) return 0;
     SeArgs a = {pooled, gate, hpre, dgate, dhpre, nullptr, nullptr, 1};
+    // (a wave-level TN formulation of these two, K = batch = 128 images, was built and measured: 51 instead of 36 us per cell
+    //  for the three launches -- ~100 waves walking 32 dependent K-steps each; the LDS-tiled GEMMs stay)
     SE_LAUNCH(4, mcp_max, se_max)
     SE_LAUNCH(5, mcp_max, se_max)
     hipLaunchKernelGGL(k_se_bias_grad, dim3(cdiv(mcp_max + se_max, 64), ng), dim3(256), 0, s, d, a);

@@ -12,6 +12,7 @@ Differences a caller can see (all optional):
     like the reference (models/model_search.py:79).
   * tensors must live on the GPU; there is no CPU path (the oracle in oracle/ is test infrastructure).
 """
+import os
 import random
 
 import torch
@@ -203,6 +204,16 @@ class MixedStage(nn.Module):
         self.register_parameter('betas', nn.Parameter(torch.zeros((self.num_res))))
 
 
+# Network.forward on the path level when it can (GPU model, fp32 storage, tfnas_amd.search.USE_PATHS): TFNAS_MODULE_PATHS=0
+# keeps the per-cell route (one autograd node per MixedOP: what the stage-by-stage tests hook into)
+MODULE_PATHS = os.environ.get('TFNAS_MODULE_PATHS', '1') != '0'
+
+
+def FN_STORAGE():
+    from . import functions
+    return functions.STORAGE
+
+
 class Network(nn.Module):
     def __init__(self, num_classes, mc_num_dddict, lat_lookup):
         super().__init__()
@@ -377,7 +388,67 @@ class Network(nn.Module):
             lb = self.classifier(self._head(xb))
         return la, lb
 
+    # ---- path level behind the module API ----------------------------------------------------------------------------
+    def _path_state(self):
+        """The SearchState (weight arena + path runner, search.py / path.py) the drop-in ``forward`` runs on: the one a caller
+        built with ``search.SearchState(model)`` if there is one (it registers itself), else a private one."""
+        from . import search
+        st = self.__dict__.get('_pstate')
+        if st is None or st.runner is None or st.model is not self:
+            st = search.SearchState(self)
+            if st.runner is None:
+                return None
+        if not st.arena.intact():                       # (p.data = ... of a different tensor: the epoch boundary)
+            st.build_paths()
+        return st
+
+    def _use_paths(self, x):
+        from . import search
+        if not (MODULE_PATHS and search.USE_PATHS and x.is_cuda and FN_STORAGE() == 'fp32'):
+            return False
+        p = self.first_stem.conv.weight
+        return p.is_cuda and p.is_leaf and p.device == x.device
+
+    def _forward_paths(self, x, sampling, mode, exp_noise, rand_pos, stem_out, pos):
+        """``forward`` on the path level (tfnas_paths_fwd / _bwd: ONE C call per direction for the 18 cells + 6 sinks instead
+        of one autograd node per cell) -- what closes the gap between the two-line import swap and tfnas_amd.search's own
+        steps.  Same kernels, bit-identical results.  Sampled mode: the cells' weight gradients are written by the backward
+        straight into the weight arena and exposed as ``.grad`` views (overwriting, like the first backward after
+        ``zero_grad()``; two backward passes through the SAME candidate without a zero_grad in between are not summed)."""
+        st = self._path_state()
+        if st is None:
+            return None
+        runner = st.runner
+        cells = self.cells()
+        if not sampling and any(p.requires_grad for p in cells[0].m_ops[0].parameters()):
+            return None                                       # soft-mode weight gradients: per-cell route
+        if sampling and torch.is_grad_enabled() and any(stg.betas.requires_grad for stg in self.stages()):
+            return None                                       # d betas of a sampled forward: per-cell route (SinkFn)
+        feat = self._stem(x) if stem_out is None else stem_out
+        if not sampling:
+            W, CL = self.arch_weights(feat.size(-1), x.device, exp_noise)
+            out, stage_lat = runner.soft(feat, W, CL)
+            lat = stage_lat.sum() + self.lat_lookup['base']
+            return self.classifier(self._head(out)), lat
+        self._prepare(feat, True, mode, exp_noise, rand_pos, pos)
+        idxs = []
+        for c in cells:
+            idxs.append(int(c._pre))
+            c.last_idx, c._pre = int(c._pre), None
+        # two sampled forwards may be alive at once (the bi-sampling pair runs gumbel, random, then ONE backward)
+        out = runner.sampled(feat, idxs, name='A' if mode == 'gumbel' else 'B', expose=st)
+        return self.classifier(self._head(out)), 0.0
+
     def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None, pos=None):
+        if self._use_paths(x):
+            try:
+                res = self._forward_paths(x, sampling, mode, exp_noise, rand_pos, stem_out, pos)
+            except BaseException:
+                for c in self.cells():
+                    c._pre = None
+                raise
+            if res is not None:
+                return res
         out_lat = self.lat_lookup['base'] if not sampling else 0.0
         # first_stem + second_stem run as one "stem cell" of the HIP library (stock PyTorch-ROCm ops cost 70 ms per
         # iteration pair here: MIOpen's fp32 NHWC path falls back to naive_conv_*, torch's BN backward is slow)

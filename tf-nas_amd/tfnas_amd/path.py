@@ -314,10 +314,12 @@ class PathRunner:
     def _wants_wgrad(self, idxs):
         return torch.is_grad_enabled() and self.cells[0].m_ops[idxs[0]].point_linear.conv.weight.requires_grad
 
-    def sampled(self, x0, idxs, name='A'):
-        """One sampled path (train_wo_arch / validate / a single bi-sampling path)."""
+    def sampled(self, x0, idxs, name='A', expose=None):
+        """One sampled path (train_wo_arch / validate / a single bi-sampling path).  ``expose``: a SearchState -- the backward
+        then points ``.grad`` of the sampled candidates' parameters at the arena ranges it wrote (module-API callers that
+        run torch's clip_grad_norm_ / optimizer.step() on ``.grad``)."""
         idxs = tuple(int(i) for i in idxs)
-        return OnePathFn.apply(self, x0, idxs, name, self._wants_wgrad(idxs))
+        return OnePathFn.apply(self, x0, idxs, name, self._wants_wgrad(idxs), expose)
 
     def bisampled(self, x0, idx_a, idx_b, side_stream):
         """Both bi-sampling paths of a weight step, interleaved on the current stream and ``side_stream``."""
@@ -390,10 +392,11 @@ class OnePathFn(torch.autograd.Function):
     """One sampled path; weight gradients go straight into the WeightArena (not through autograd)."""
 
     @staticmethod
-    def forward(ctx, runner, x0, idxs, name, need_w):          # (grad mode is off inside forward: need_w comes from outside)
+    def forward(ctx, runner, x0, idxs, name, need_w, expose=None):   # (grad mode is off inside forward: need_w comes from outside)
         _require_cuda(x0, 'path input')
         x0h = _nhwc(x0)
         dev = x0h.device
+        ctx.expose, ctx.idxs, ctx.need_w = expose, idxs, need_w
         s = runner._plan(name, idxs, x0h, need_w, ctx.needs_input_grad[1], False)
         out = _out_tensor(s, x0h.shape[0], dev)
         cur = torch.cuda.current_stream(dev)
@@ -417,7 +420,9 @@ class OnePathFn(torch.autograd.Function):
             runner._bwd(*args, stage_begin=0, stage_end=k)
         else:
             runner._bwd(*args)
-        return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None
+        if ctx.expose is not None and ctx.need_w:
+            ctx.expose.expose_weight_grads([ctx.idxs], track=False)
+        return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None, None
 
 
 class BiPathFn(torch.autograd.Function):

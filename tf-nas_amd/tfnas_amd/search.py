@@ -94,6 +94,9 @@ class SearchState:
         # accumulated in place into zeroed arena views
         self._shared = [p for p in self.weights if id(p) not in cell_params]
         self._shared_spans = _merge_spans([self.arena.slot[id(p)] for p in self._shared])
+        # the drop-in Network.forward (model_search.Network._path_state) runs on THIS state instead of building a second
+        # arena that would fight over the parameters' storages
+        self.model.__dict__['_pstate'] = self
 
     # ---- fused optimizer steps (opt_kernels.hip) -------------------------------------------------------------------
     def _bind_momentum(self, opt_w):
@@ -371,14 +374,17 @@ class SearchState:
         for p in self._shared:
             p.grad = self.arena.grad_view(p)
 
-    def expose_weight_grads(self, idx_lists):
-        """After backward: point .grad of the sampled candidates' parameters at the arena ranges the kernels wrote."""
+    def expose_weight_grads(self, idx_lists, track=True):
+        """After backward: point .grad of the sampled candidates' parameters at the arena ranges the kernels wrote.
+        ``track``: remember them so that the next path-level w-step drops the views again (begin_weight_grads); the module-API
+        route (Network.forward on the path level) leaves that to the caller's zero_grad()."""
         g = self._graded
         for idxs in idx_lists:
             for ci, idx in enumerate(idxs):
                 for p in self.op_params(ci, idx):
                     p.grad = self.arena.grad_view(p)
-                    g.append(p)
+                    if track:
+                        g.append(p)
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (chosen once per device)."""
