@@ -50,6 +50,8 @@ struct PathCtx {
     hipEvent_t wdone[TFNAS_MAX_CELLS];
     hipEvent_t join = nullptr, xfork = nullptr;
     bool events_ok = false;
+    bool defer_join = false;           // tfnas_path_defer_join: tfnas_paths_bwd leaves the side stream(s) un-joined
+    bool join_pending = false;
 };
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -307,6 +309,35 @@ extern "C" int tfnas_path_set_side_stream2(void* ctx, void* stream) {
     return 0;
 }
 
+static int join_sides(PathCtx* c, hipStream_t s) {
+    hipError_t e = hipEventRecord(c->join, c->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join, 0);
+    if (e == hipSuccess && c->side2) {
+        e = hipEventRecord(c->xfork, c->side2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->xfork, 0);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->side);
+        if (c->side2) (void)hipStreamSynchronize(c->side2);
+    }
+    c->join_pending = false;
+    return (int)e;
+}
+
+extern "C" int tfnas_path_defer_join(void* ctx, int on) {
+    PathCtx* c = static_cast<PathCtx*>(ctx);
+    if (!c) return TFNAS_ENULL;
+    c->defer_join = on != 0;
+    return 0;
+}
+
+extern "C" int tfnas_path_join(void* ctx, void* stream) {
+    PathCtx* c = static_cast<PathCtx*>(ctx);
+    if (!c) return TFNAS_ENULL;
+    if (!c->join_pending || !c->events_ok) return 0;
+    return join_sides(c, S(stream));
+}
+
 extern "C" int tfnas_path_plan(void* ctx, const TfnasPathDesc* pd, TfnasPathWs* ws) {
     if (!ctx || !pd) return TFNAS_ENULL;
     return plan_path(*static_cast<PathCtx*>(ctx), *pd, ws);
@@ -494,21 +525,19 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         for (int j = sg.ncell - 1; j >= 0 && rc == 0; --j)
             for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_cell(run[p], sg.first_cell + j);
     }
-    // join every side stream (also on an error path: the caller frees / reuses the arena next)
+    // join every side stream (also on an error path: the caller frees / reuses the arena next) -- unless the caller asked to
+    // do that itself later (tfnas_path_defer_join): the weight gradients are leaves, only the optimizer step consumes them,
+    // and whatever the caller enqueues next on the path's stream (the stem's backward) need not wait for the last cells'
+    // weight-gradient kernels
     for (int p = 0; p < npath; ++p) {
         BwdRun& r = run[p];
         if (!r.side_on) continue;
-        hipError_t e = hipEventRecord(r.c->join, r.c->side);
-        if (e == hipSuccess) e = hipStreamWaitEvent(r.s, r.c->join, 0);
-        if (e == hipSuccess && r.c->side2) {
-            e = hipEventRecord(r.c->xfork, r.c->side2);
-            if (e == hipSuccess) e = hipStreamWaitEvent(r.s, r.c->xfork, 0);
+        if (r.c->defer_join && rc == 0) {
+            r.c->join_pending = true;
+            continue;
         }
-        if (e != hipSuccess) {
-            (void)hipStreamSynchronize(r.c->side);
-            if (r.c->side2) (void)hipStreamSynchronize(r.c->side2);
-            if (rc == 0) rc = (int)e;
-        }
+        const int e = join_sides(r.c, r.s);
+        if (e != 0 && rc == 0) rc = e;
     }
     return rc;
 }

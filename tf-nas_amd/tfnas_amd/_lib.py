@@ -87,6 +87,8 @@ _PROTOS = {
     'tfnas_path_set_side_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_path_set_side_stream2': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_set_stats_sync': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    'tfnas_path_defer_join': (C.c_int, [C.c_void_p, C.c_int]),
+    'tfnas_path_join': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_path_plan': (C.c_int, [C.c_void_p, C.POINTER(TfnasPathDesc), C.POINTER(TfnasPathWs)]),
     'tfnas_paths_fwd': (C.c_int, [C.c_int] + [_PP] * 8),
     'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11 + [C.c_int, C.c_int]),

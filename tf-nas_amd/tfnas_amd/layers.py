@@ -5,8 +5,8 @@ Only what the search hot path touches is provided:
                       (``inverted_bottleneck.conv``, ``depth_conv.conv``, ``squeeze_excite.conv_reduce/conv_expand``,
                       ``point_linear.conv``) so that train_search.py:164-193's ``exec`` weight slicing and the
                       state_dict keys (:244-258) keep working.  Its arithmetic runs in the HIP library.
-  ConvLayer / LinearLayer (models/layers.py:190-271, :322-428) -- stems and head; SURVEY.md section 8(a) a9 leaves
-                      these 1.6 % of the MACs to stock PyTorch-ROCm ops.
+  ConvLayer / LinearLayer (models/layers.py:190-271, :322-428) -- parameter containers of the stems and the head; inside
+                      Network they run as HIP cells (TFNAS_MODE_STEM / _HEAD), the classifier is an nn.Linear.
   Swish               (models/layers.py:26-35)
 BatchNorm of the search net has no affine and no running statistics (layers.py:101-103,469,498,533): it is
 a pure function of the batch and therefore has no module/state here.
@@ -29,27 +29,13 @@ class Swish(nn.Module):
         return x.mul_(x.sigmoid()) if self.inplace else x * x.sigmoid()
 
 
-def _bn(x):
-    return F.batch_norm(x, None, None, None, None, True, 0.0, BN_EPS)
-
-
-def _act(x, act_func):
-    if act_func == 'relu':
-        return F.relu(x)
-    if act_func == 'swish':
-        return x * torch.sigmoid(x)
-    if act_func is None:
-        return x
-    raise ValueError('unsupported act_func: %s' % act_func)
-
-
 def get_same_padding(kernel_size):
     assert kernel_size % 2 > 0, 'kernel size should be odd number'
     return kernel_size // 2
 
 
 class ConvLayer(nn.Module):
-    """conv -> BN(batch stats, no affine) -> act; stems/head only (stock PyTorch-ROCm ops)."""
+    """conv -> BN -> act of the stems / head: the parameter container (the arithmetic runs in Network's stem / head HIP cells)."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, affine=False, act_func='relu'):
         super().__init__()
@@ -66,23 +52,12 @@ class ConvLayer(nn.Module):
         return 'ConvLayer'
 
     def forward(self, x):
-        # Network.forward never comes here (stems and head run as HIP cells, model_search.py / model_eval.py); this body
-        # serves callers that invoke the layer on its own.  Like everything else in the package it has no CPU path.
-        if not x.is_cuda:
-            raise RuntimeError('tfnas_amd: ConvLayer input must live on the GPU (no CPU implementation)')
-        if self.affine:
-            return _act(self.bn(self.conv(x)), self.act_func)
-        if self.kernel_size > 1 and self.in_channels <= 4:
-            # image stem (3 input channels): im2col + one GEMM; rocBLAS handles this far better than MIOpen's
-            # fp32 3-channel wgrad (tools/stem_bench.py: 3.7 ms vs 12.6 ms fwd+wgrad at batch 128)
-            N, _, H, W = x.shape
-            k, s, p = self.kernel_size, self.stride, get_same_padding(self.kernel_size)
-            Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-            cols = F.unfold(x, k, padding=p, stride=s)
-            y = torch.matmul(self.conv.weight.view(self.out_channels, -1), cols).view(N, self.out_channels, Ho, Wo)
-        else:
-            y = self.conv(x)
-        return _act(_bn(y), self.act_func)
+        # Inside Network (search and derived) the stems and the feature-mix head run as HIP cells (TFNAS_MODE_STEM / _HEAD:
+        # model_search.Network._stem / _head, model_eval._DerivedBase); this module is their parameter container.  There is
+        # deliberately NO stock-torch body here: a caller invoking the layer on its own would silently get MIOpen / rocBLAS
+        # arithmetic instead of the HIP path.
+        raise RuntimeError('tfnas_amd: ConvLayer runs only as part of Network (stem / head HIP cells: Network._stem, '
+                           'Network._head); it has no standalone forward')
 
 
 class LinearLayer(nn.Module):
@@ -150,18 +125,10 @@ class MBInvertedResBlock(nn.Module):
         return ps
 
     def _stem_forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError('tfnas_amd: MBInvertedResBlock input must live on the GPU (no CPU implementation)')
-        if self.affine:
-            raise RuntimeError('tfnas_amd: the derived network runs its stem through model_eval.Network._stem')
-        res = x
-        y = _act(_bn(self.depth_conv.conv(x)), self.act_func)
-        if self.squeeze_excite is not None:
-            s = F.adaptive_avg_pool2d(y, 1)
-            s = self.squeeze_excite.conv_expand(_act(self.squeeze_excite.conv_reduce(s), self.act_func))
-            y = y * torch.sigmoid(s)
-        y = _bn(self.point_linear.conv(y))
-        return y + res if self.has_residual else y
+        # second_stem (mid == in: no expand convolution) runs fused with first_stem as ONE stem cell of the HIP library
+        # (Network._stem); no stock-torch body on purpose (see ConvLayer.forward)
+        raise RuntimeError('tfnas_amd: an MBInvertedResBlock without expand convolution (second_stem) runs only as part of '
+                           'Network._stem; it has no standalone forward')
 
     def forward(self, x):
         if self.inverted_bottleneck is None:

@@ -145,6 +145,22 @@ class PathRunner:
         except Exception:
             pass
 
+    # ---- deferred join of the weight-gradient streams ------------------------------------------------------------------
+    def defer_joins(self, names, on):
+        """tfnas_path_defer_join for the slots ``names`` (created on demand)."""
+        for n in names:
+            s = self._slot(n)
+            if getattr(s, 'deferred', False) != bool(on):
+                check(self.lib.tfnas_path_defer_join(s.ctx, int(bool(on))), 'tfnas_path_defer_join')
+                s.deferred = bool(on)
+
+    def join(self, names, streams):
+        """Join the weight-gradient streams of the slots ``names`` to ``streams`` (one per slot) -- before the optimizer step."""
+        for n, st in zip(names, streams):
+            s = self._slots.get(n)
+            if s is not None and getattr(s, 'deferred', False):
+                check(self.lib.tfnas_path_join(s.ctx, C.c_void_p(st.cuda_stream)), 'tfnas_path_join')
+
     # ---- descriptor templates ---------------------------------------------------------------------------------
     def _template(self, ci, idx, N, H, W):
         """Planned TfnasCellDesc of cell ``ci`` with candidate ``idx`` (None: all 8; a pair: the two bi-sampling candidates
@@ -396,7 +412,7 @@ class OnePathFn(torch.autograd.Function):
         _require_cuda(x0, 'path input')
         x0h = _nhwc(x0)
         dev = x0h.device
-        ctx.expose, ctx.idxs, ctx.need_w = expose, idxs, need_w
+        ctx.expose, ctx.idxs, ctx.need_w, ctx.name = expose, idxs, need_w, name
         s = runner._plan(name, idxs, x0h, need_w, ctx.needs_input_grad[1], False)
         out = _out_tensor(s, x0h.shape[0], dev)
         cur = torch.cuda.current_stream(dev)
@@ -421,6 +437,7 @@ class OnePathFn(torch.autograd.Function):
         else:
             runner._bwd(*args)
         if ctx.expose is not None and ctx.need_w:
+            runner.join([ctx.name], [cur])            # (a slot a search.w_step left in deferred-join mode: join now)
             ctx.expose.expose_weight_grads([ctx.idxs], track=False)
         return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None, None
 

@@ -503,6 +503,10 @@ PICK_STREAMS = os.environ.get('TFNAS_PICK_STREAMS', '1') != '0'
 # 19.1 ms): it is bound by the length of ONE chain of ~1000 dependent launches + the weight-gradient queue, and with the two
 # paths merged nothing overlaps that chain's per-launch latencies any more.
 DUAL_PATHS = os.environ.get('TFNAS_DUAL', '0') == '1'
+# w-step: 1 = join the weight-gradient streams right before the optimizer step instead of at the end of the path's backward, so
+# that the stem's backward overlaps with the last cells' weight-gradient kernels.  Measured at B = 128: no effect (18.57 vs
+# 18.43-18.47 ms per w-step, pair unchanged: the stem's backward then shares the chip with those kernels) -- off by default.
+DEFER_JOIN = os.environ.get('TFNAS_DEFER_JOIN', '0') == '1'
 DUAL_WGRAD_STREAMS = int(os.environ.get('TFNAS_DUAL_WGRAD_STREAMS', '2'))     # weight-gradient queues of the dual mode (1 or 2)
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
@@ -667,6 +671,16 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         runner = state.runner
     cells = model.cells()
     T = cells[0].T
+    fused = FUSED_OPT and state._fusable_sgd(opt_w)
+    if not fused or state._need_zero_grad:
+        opt_w.zero_grad()                   # (750 parameters; the fused route never leaves a stale .grad behind)
+        state._need_zero_grad = False
+    state.begin_weight_grads()
+    # The stems have no candidates: their forward is enqueued BEFORE the sampled indices are known.  After an alpha-step the
+    # host has to wait for the staged copy of the new log_alphas (alpha_host below) -- i.e. for the GPU to finish that step --
+    # before it can sample and plan the paths; with the stem already queued the GPU works through it (0.65 ms at B = 128)
+    # while the host does that, instead of idling (0.4 ms per pair in the traces).
+    feat = model._stem(x)
     if host_e is not None:
         model._require_all_switches_on()
         pos_g = host_gumbel_positions(state.alpha_host(), host_e, T)
@@ -682,14 +696,13 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         model.reset_switches()
     for c, ia in zip(cells, idx_a if idx_b is None else idx_b):
         c.last_idx = ia
-    fused = FUSED_OPT and state._fusable_sgd(opt_w)
     if fused:
         state.dp_begin([idx_a] if idx_b is None else [idx_a, idx_b], group)
-    if not (FUSED_OPT and state._fusable_sgd(opt_w)) or state._need_zero_grad:
-        opt_w.zero_grad()                   # (750 parameters; the fused route never leaves a stale .grad behind)
-        state._need_zero_grad = False
-    state.begin_weight_grads()
-    feat = model._stem(x)
+    # the path's backward leaves its weight-gradient streams un-joined (they are joined right before the optimizer step
+    # below), so the stem's backward overlaps with the last cells' weight-gradient kernels -- not with a gradient all-reduce
+    # hook armed (it packs the late stages' gradients between the two backward segments)
+    slots = (['AB'] if DUAL_PATHS else ['A', 'B']) if bi_sampling else ['A']
+    runner.defer_joins(slots, DEFER_JOIN and fused and runner.segment_hook is None)
     if bi_sampling and DUAL_PATHS:
         # both paths through one launch per kernel (TfnasPathDesc.dual), everything on the current stream
         state.side_stream(dev)                  # (picks the weight-gradient side stream on first use)
@@ -711,6 +724,8 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
         loss = F.cross_entropy(logits_g, target)
     loss.backward()
+    cur = torch.cuda.current_stream(dev)
+    runner.join(slots, [cur] * len(slots))      # (no-op unless deferred: everything below reads the weight gradients)
     idx_lists = [idx_a] if idx_b is None else [idx_a, idx_b]
     if FUSED_OPT and state._fusable_sgd(opt_w):
         if state.expose_grads:

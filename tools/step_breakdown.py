@@ -46,7 +46,7 @@ with torch.no_grad():
     xs = x
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        h = model.second_stem(model.first_stem(xs))
+        h = model._stem(xs)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         print('stems fwd total %.2f ms' % ((t1 - t0) * 1e3))
 import cProfile, pstats
