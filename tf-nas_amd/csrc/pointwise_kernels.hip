@@ -217,16 +217,19 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
 
 // dwmix[g] = d loss / d wmix[g] = <dout, phat_g [+ x]> = sum_o S2[g][o] [+ <dout,x>]
 // resdot[o] = per-channel <dout,x> sums (residual cells), stored right after red3
-__global__ void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const double* __restrict__ resdot,
-                         float* __restrict__ dwmix) {
-    const int g = threadIdx.x;
-    if (g < d.G) {
-        double s = 0.0;
-        if (d.has_res)
-            for (int o = 0; o < d.oc; ++o) s += resdot[o];
-        for (int o = 0; o < d.oc; ++o) s += red3[2 * ((size_t)g * d.oc + o) + 1];
-        dwmix[g] = (float)s;
+__global__ __launch_bounds__(64) void k_mix_dw(TfnasCellDesc d, const double* __restrict__ red3, const double* __restrict__ resdot,
+                                               float* __restrict__ dwmix) {
+    // one wave per group (blockIdx.x), lanes stride over the output channels, butterfly sum in double (fixed order).  The
+    // first version -- ONE thread per group walking up to 640 doubles -- took 15 us on the alpha-step's dependency chain.
+    const int g = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int o = lane; o < d.oc; o += 64) {
+        s += red3[2 * ((size_t)g * d.oc + o) + 1];
+        if (d.has_res) s += resdot[o];
     }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) dwmix[g] = (float)s;
 }
 
 // ============================================================================ BN2 backward sums, fused with the SE pool backward
@@ -717,7 +720,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
 
 int launch_mix_dw(const TfnasCellDesc& d, const double* red3, const double* resdot, float* dwmix, hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);
-    hipLaunchKernelGGL(k_mix_dw, dim3(1), dim3(64), 0, s, d, red3, resdot, dwmix);
+    hipLaunchKernelGGL(k_mix_dw, dim3(d.G), dim3(64), 0, s, d, red3, resdot, dwmix);
     return (int)hipGetLastError();
 }
 
