@@ -318,6 +318,12 @@ static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     return 0;
 }
 
+int launch_pending_expand(PendingExpand& p, hipStream_t s) {
+    if (!p.valid) return 0;
+    p.valid = false;
+    return launch_expand_wgrad(p.d, p.dEh, p.E, p.cb1, p.x, p.part_w, s);
+}
+
 int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdBufs& b0, hipStream_t s, const CellSide* so) {
     const TfnasBnAffine* bn = b0.bn;
     TfnasCellDesc dc = d0;
@@ -362,7 +368,8 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
     if (!b.dx && !d.need_wgrad) return 0;
     // weight gradients: on the side stream, scratch = part_w
-    if (d.need_wgrad)
+    const bool merged = so && so->side && so->merged && so->pend;
+    if (d.need_wgrad && !merged)
         TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, fork_to(so, 0, s)));
     TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s)); // dZ = dP W_proj
     const bool fused2 = bn2_fused_fits(d);
@@ -378,6 +385,10 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
         // host-bound w-step; cells without SE launch nothing for it)
         hipStream_t sw = fork_to(so, 1, s);
+        if (merged) {
+            TRY(launch_pending_expand(*so->pend, sw));          // the previous cell's expand weight gradient
+            TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, sw));
+        }
         if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
         TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
     }
@@ -391,7 +402,16 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     } else {
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
     }
-    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
+    if (d.need_wgrad) {
+        if (merged) {
+            PendingExpand& p = *so->pend;
+            p.valid = true;
+            p.d = d;
+            p.dEh = b.dEh; p.E = b.E; p.cb1 = cb1; p.x = b.x; p.part_w = part_w;
+        } else {
+            TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
+        }
+    }
     if (b.dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
         float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);

@@ -62,6 +62,15 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
         if (_r != 0) return _r; \
     } while (0)
 
+// TFNAS_MERGE_FORKS=1: ONE fork per cell instead of three (cell_impl.h: CellSide::merged).  Off by default -- measured at
+// B = 128 (LAG = 3): 18.53 / 18.67 vs 18.43 / 18.55 ms per weight step: the 11-16 us a fork costs the data-gradient chain are
+// not on the critical path (the weight-gradient queue finishes last either way), and the later start of a cell's project /
+// depthwise weight gradients costs what the saved event records buy.
+bool forks_merged() {
+    static const int on = [] { const char* e = getenv("TFNAS_MERGE_FORKS"); return (e && e[0] == '1') ? 1 : 0; }();
+    return on == 1;
+}
+
 bool wgrad_side_enabled() {
     static int on = -1;
     if (on < 0) {
@@ -398,13 +407,18 @@ struct BwdRun {
     float *dx0, *dwmix, *dcell_lat;
     hipStream_t s;
     bool side_on;
+    bool merged;                 // one fork per cell (cell_impl.h: CellSide::merged)
+    PendingExpand pend;
 };
 
 // before cell i (or the sink step in front of it) reuses scratch set i % NSET and ring slot (i+1) % NRING, the
 // weight-gradient kernels of cell i + NSET -- the last ones that read them -- must be done (side stream, <= LAG cells behind)
 int wait_wgrads(BwdRun& r, int i) {
-    const int j = i + NSET;
-    if (!r.side_on || j >= r.c->pd.ncell || !r.c->pd.cell[j].need_wgrad) return 0;
+    // (merged forks: cell j's expand weight gradient is launched inside cell j-1's call, so the event that covers ALL of cell
+    //  j's weight-gradient kernels is wdone[j - 1] -- later on the same stream than wdone[j])
+    const int j = i + NSET - (r.merged ? 1 : 0);
+    if (!r.side_on || j >= r.c->pd.ncell || j < 0 || !r.c->pd.cell[j].need_wgrad) return 0;
+    if (r.merged && j <= i) return 0;
     return (int)hipStreamWaitEvent(r.s, r.c->wdone[j], 0);
 }
 
@@ -470,6 +484,8 @@ int bwd_cell(BwdRun& r, int i) {
     if (side) {
         so.side = (c.side2 && (i & 1)) ? c.side2 : c.side;
         for (int k = 0; k < 3; ++k) so.fork[k] = c.fork[i][k];
+        so.merged = r.merged;
+        so.pend = &r.pend;
     }
     TRY(cell_bwd_impl(pd.cell[i], c.cws[i], b, r.s, side ? &so : nullptr));
     if (side) HIP_TRY(hipEventRecord(c.wdone[i], so.side));
@@ -511,6 +527,8 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         for (int i = 0; i < c->pd.ncell; ++i) any_w = any_w || c->pd.cell[i].need_wgrad;
         r.side_on = wgrad_side_enabled() && any_w;
         if (r.side_on) TRY(ensure_side(c));
+        r.merged = r.side_on && forks_merged() && !c->side2;
+        r.pend.valid = false;
     }
     const PathCtx* c0 = run[0].c;
     int lat_off_end = 0;
@@ -524,6 +542,15 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_sink(run[p], st, lat_off);
         for (int j = sg.ncell - 1; j >= 0 && rc == 0; --j)
             for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_cell(run[p], sg.first_cell + j);
+    }
+    // merged forks: the last cell's expand weight gradient still waits for its fork
+    for (int p = 0; p < npath && rc == 0; ++p) {
+        BwdRun& r = run[p];
+        if (!r.merged || !r.pend.valid) continue;
+        hipError_t e = hipEventRecord(r.c->xfork, r.s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(r.c->side, r.c->xfork, 0);
+        if (e != hipSuccess) { rc = (int)e; break; }
+        rc = launch_pending_expand(r.pend, r.c->side);
     }
     // join every side stream (also on an error path: the caller frees / reuses the arena next) -- unless the caller asked to
     // do that itself later (tfnas_path_defer_join): the weight gradients are leaves, only the optimizer step consumes them,
