@@ -25,7 +25,7 @@ import test_gpu_cell as t
 import _hipcheck as hc
 from tfnas_amd.functions import MixedOpFn
 out = {}
-for name in ('real_s1b2_56', 'real_s2b2_28', 'real_s4b2_14'):
+for name in os.environ.get('CHILD_CFGS', 'real_s1b2_56,real_s2b2_28,real_s4b2_14').split(','):
     cfg = [c for c in t.CONFIGS if c[0] == name][0]
     for idxs, wg in ((list(range(8)), False), ([5], True), ([0], True)):
         o, m, x, r, e = t._inputs(cfg)
@@ -94,6 +94,27 @@ def test_streaming_depthwise_equals_tiled_and_side_stream_is_bit_identical(tmp_p
         a, b = base[k].double(), tiled[k].double()
         tol = 2e-5 * float(b.abs().max()) + 1e-6                                        # other summation order only
         assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+
+
+def test_register_window_depthwise_kernels_equal_the_lds_kernels(tmp_path):
+    """csrc/dw_direct.inc (forward, backward w.r.t. the input and weight gradient of the depthwise conv as register-window
+    kernels without LDS staging) forced on EVERY cell vs the LDS-tiled / ring kernels (TFNAS_DW_DIRECT=0): same products, other
+    summation orders (the statistics partials are grouped differently too).  Stride 1 and 2, k3 / k5, ReLU / swish, SE,
+    image edges that cut a lane's column block, images smaller than a wave's column span."""
+    cfgs = ('real_s1b1_112,real_s1b2_56,real_s3b1_28,real_s4b2_14,real_s5b1_14,real_s5b2_7,tiny_s2_swish_odd,'
+            'wide_tile_edge,tiny_7x7,tiny_s1_relu_res,tiny_s2_relu')
+    base = _run_child(tmp_path, 'lds', {'TFNAS_DW_DIRECT': '0', 'CHILD_CFGS': cfgs})
+    for jw in ('2', '4'):
+        direct = _run_child(tmp_path, 'direct' + jw, {'TFNAS_DWD_FWD': '1', 'TFNAS_DWD_BWD': '1', 'TFNAS_DWD_WGRAD': '1',
+                                                      'TFNAS_DWD_JW': jw, 'CHILD_CFGS': cfgs})
+        assert base.keys() == direct.keys() and len(base) > 80
+        differs = 0
+        for k in base:
+            a, b = direct[k].double(), base[k].double()
+            tol = 5e-5 * float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= tol, (jw, k, float((a - b).abs().max()), tol)
+            differs += int(not torch.equal(direct[k], base[k]))
+        assert differs > 40                                       # the switches really selected other kernels
 
 
 def test_wave_level_tn_weight_gradients_equal_the_lds_tiled_kernels(tmp_path):

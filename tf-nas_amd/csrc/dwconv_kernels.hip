@@ -779,4 +779,16 @@ static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const 
     return (int)hipGetLastError();
 }
 
+static int launch_dw_wgrad_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
+                                  const float* D, const double* stats2, const double* red2, const float* E,
+                                  const double* stats1, float* part, size_t out_size, hipStream_t s, bool& done);
+static bool dwd_enabled();
+static int launch_dw_bwd_data_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
+                                     const float* D, const double* stats2, const double* red2, const float* E,
+                                     const double* stats1, float* dEh, double* red1, float* part, hipStream_t s, float* cb1,
+                                     bool& done);
+static int launch_dw_fwd_direct(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
+                                float* part, hipStream_t s, bool& done);
+
 #include "dw_stream.inc"
+#include "dw_direct.inc"

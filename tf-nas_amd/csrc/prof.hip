@@ -23,7 +23,7 @@ void ProfScope::stop() {
     on = false;
     hipEvent_t e1;
     if (hipEventCreate(&e1) != hipSuccess) return;
-    hipEventRecord(e1, s);
+    (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_mu);
     g_ev[id].emplace_back(e0, e1);
 }
@@ -44,8 +44,8 @@ extern "C" int tfnas_prof_collect(int id, uint64_t* launches, double* total_ms) 
         float ms = 0.f;
         hipError_t e = hipEventSynchronize(pr.second);
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
         if (e != hipSuccess) return (int)e;
         *launches += 1;
         *total_ms += ms;

@@ -507,6 +507,7 @@ DUAL_PATHS = os.environ.get('TFNAS_DUAL', '0') == '1'
 # that the stem's backward overlaps with the last cells' weight-gradient kernels.  Measured at B = 128: no effect (18.57 vs
 # 18.43-18.47 ms per w-step, pair unchanged: the stem's backward then shares the chip with those kernels) -- off by default.
 DEFER_JOIN = os.environ.get('TFNAS_DEFER_JOIN', '0') == '1'
+HEADS_ON_MAIN = os.environ.get('TFNAS_HEADS_ON_MAIN', '1') == '1'
 DUAL_WGRAD_STREAMS = int(os.environ.get('TFNAS_DUAL_WGRAD_STREAMS', '2'))     # weight-gradient queues of the dual mode (1 or 2)
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
@@ -715,11 +716,17 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         oa, ob = runner.bisampled(feat, idx_a, idx_b, side)
         logits_g = model.classifier(model._head(oa))
         loss = F.cross_entropy(logits_g, target)
-        with torch.cuda.stream(side):
-            loss_r = F.cross_entropy(model.classifier(model._head(ob)), target)
-        cur.wait_stream(side)
-        loss_r.record_stream(cur)
-        loss = loss + loss_r
+        if HEADS_ON_MAIN:
+            # both heads on the current stream: the shared head / classifier parameters then accumulate their two gradients on
+            # the stream their AccumulateGrad nodes live on (no cross-stream accumulation, no autograd warning about it)
+            cur.wait_stream(side)
+            loss = loss + F.cross_entropy(model.classifier(model._head(ob)), target)
+        else:
+            with torch.cuda.stream(side):
+                loss_r = F.cross_entropy(model.classifier(model._head(ob)), target)
+            cur.wait_stream(side)
+            loss_r.record_stream(cur)
+            loss = loss + loss_r
     else:
         logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
         loss = F.cross_entropy(logits_g, target)

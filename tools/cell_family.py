@@ -39,7 +39,10 @@ for ci in want:
     so = (size - 1) // s + 1
     P, Po = B * size * size, B * so * so
     x = torch.randn(B, ic, size, size, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    for label, idxs in (('soft', tuple(range(8))), ('samp5', (5,))):
+    labels = (('soft', tuple(range(8))), ('samp5', (5,)))
+    if os.environ.get('CF_SAMPLED_ONLY') == '1':
+        labels = tuple(('samp%d' % int(i), (int(i),)) for i in os.environ.get('CF_IDX', '2,5').split(','))
+    for label, idxs in labels:
         plan = blk._plan(idxs)
         ps = plan.params()
         for p in ps:
@@ -63,7 +66,7 @@ for ci in want:
         tot = sum(v[1] for v in fam.values()) / n
         flops = {'k_expand_fwd': 2.0 * P * ic * M, 'k_expand_dgrad': 2.0 * P * ic * M, 'k_expand_wgrad': 2.0 * P * ic * M,
                  'k_project_fwd': 2.0 * Po * M * oc, 'k_project_dgrad': 2.0 * Po * M * oc, 'k_project_wgrad': 2.0 * Po * M * oc}
-        print('cell %2d %d->%d s%d %dx%d  %-5s M=%d  total %.3f ms' % (ci, ic, oc, s, size, size, label, M, tot))
+        print('cell %2d %d->%d s%d %dx%d  %-5s M=%d  total %.3f ms   E %.1f MB  D %.1f MB' % (ci, ic, oc, s, size, size, label, M, tot, P * M * 4e-6, Po * M * 4e-6))
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
             ms = v[1] / n
             extra = '  %6.1f TF/s' % (flops[k] / (ms * 1e-3) / 1e12) if k in flops else ''
