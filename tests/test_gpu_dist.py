@@ -276,8 +276,12 @@ def test_sync_stats_two_ranks_equal_one_rank_at_the_global_batch(tmp_path):
         err, ref = float((b - a).abs().max()), float(a.abs().max())
         assert err <= 1e-5 + 2e-4 * ref, (k, err, ref)
     assert abs(one['lat'] - r0['search']['lat']) < 1e-4
-    for a, b in zip(one['grads'], r0['search']['grads']):
-        assert torch.allclose(b, a, atol=2e-5), float((b - a).abs().max())
+    for i, (a, b) in enumerate(zip(one['grads'], r0['search']['grads'])):
+        # the first two entries are the log_alphas of the ReLU stage (112 x 112 / 56 x 56 cells): statistics summed in another
+        # order (4 + 4 images vs 8, other kernels' partial-row grouping) move pre-activations within fp32 rounding of 0 across
+        # the ReLU kink -- observed 1e-5 .. 1e-4 there against 1e-8 .. 2e-6 on every other cell (tools/dbg_dwd.py)
+        atol = 5e-4 if i < 2 else 2e-5
+        assert torch.allclose(b, a, atol=atol), (i, float((b - a).abs().max()))
     for a, b in zip(one['arch'], r0['search']['arch']):
         assert torch.allclose(b, a, atol=1e-4)
     ref = _retrain_step_state(X, Y, 1, 0, False)

@@ -26,7 +26,11 @@ import _hipcheck as hc
 from tfnas_amd.functions import MixedOpFn
 out = {}
 for name in os.environ.get('CHILD_CFGS', 'real_s1b2_56,real_s2b2_28,real_s4b2_14').split(','):
+    name, _, nover = name.partition('@')                       # 'config@N': the config at another batch size
     cfg = [c for c in t.CONFIGS if c[0] == name][0]
+    if nover:
+        cfg = cfg[:7] + (int(nover),) + cfg[8:]
+        name += '@' + nover
     for idxs, wg in ((list(range(8)), False), ([5], True), ([0], True)):
         o, m, x, r, e = t._inputs(cfg)
         plan = m._plan(tuple(idxs))
