@@ -244,14 +244,14 @@ __global__ __launch_bounds__(64) void k_mix_dw(TfnasCellDesc d, const double* __
 template <int ACT>
 __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* __restrict__ dZ, const float* __restrict__ D,
                                                   const double* __restrict__ stats2, float* __restrict__ dgate,
-                                                  float* __restrict__ pp) {
+                                                  float* __restrict__ pp, int CH) {
     __shared__ f32x4 buf[256];
     int g, c0;
-    if (!chunk_locate(d, blockIdx.y, 64, false, g, c0)) return;
+    if (!chunk_locate(d, blockIdx.y, CH, false, g, c0)) return;
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
     const bool has_se = d.g[g].se > 0;
     const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x;
-    const int nq = (min(64, mcp - c0) + 3) >> 2, cqs = nq <= 4 ? 2 : (nq <= 8 ? 3 : 4), CQN = 1 << cqs, RLN = 256 >> cqs;
+    const int nq = (min(CH, mcp - c0) + 3) >> 2, cqs = nq <= 4 ? 2 : (nq <= 8 ? 3 : 4), CQN = 1 << cqs, RLN = 256 >> cqs;
     const int tid = threadIdx.x, cq = tid & (CQN - 1), rl = tid >> cqs;       // (see k_se_pool)
     const int ch = c0 + 4 * cq;
     const bool active = ch < mcp;
@@ -749,8 +749,13 @@ bool bn2_fused_fits(const TfnasCellDesc& d) { return 4 * (size_t)d.N * d.M <= TF
 int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, float* dgate,
                     float* pp, hipStream_t s) {
     ProfScope _prof(TK_SE_BWD_REDUCE, s);
-    dim3 grid(d.N, chunk_count(d, 64, false));
-    ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_bn2_pool<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, dgate, pp); })
+    // 32-channel chunks (one 128-byte line per pixel) where 64-channel ones leave the chip under-filled: the sampled launches
+    // of the 112 x 112 ... 28 x 28 cells are N x (1..4) workgroups of 0.2-1.6 MB each
+    static const int ch_env = getenv("TFNAS_BN2POOL_CH") ? atoi(getenv("TFNAS_BN2POOL_CH")) : 0;
+    int CH = (d.N * chunk_count(d, 64, false) < 1024 && d.Ho * d.Wo >= 196) ? 32 : 64;
+    if (ch_env == 32 || ch_env == 64) CH = ch_env;
+    dim3 grid(d.N, chunk_count(d, CH, false));
+    ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_bn2_pool<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, dgate, pp, CH); })
     return (int)hipGetLastError();
 }
 

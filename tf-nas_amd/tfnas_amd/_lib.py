@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtfnas_hip.so')
+LIB_PATH = os.environ.get('TFNAS_LIB') or os.path.join(_HERE, 'libtfnas_hip.so')     # (TFNAS_LIB: an experiment build of the same ABI)
 LIB_PATH_BF16 = os.path.join(_HERE, 'libtfnas_hip_bf16.so')     # same sources + the bf16-storage mode (csrc/Makefile)
 
 MAX_GROUPS, MAX_SINK, MAX_CELLS = 8, 4, 32
