@@ -8,7 +8,7 @@
  * device pointers.  Each entry point cites the reference code whose arithmetic it replaces.
  *
  * Conventions
- *  - all tensors are fp32 (the four [pixels][M] stream tensors optionally bf16, TfnasCellDesc.stor), activations are NHWC
+ *  - all tensors are fp32, activations are NHWC
  *    ("channels_last"): x[n][h][w][c], c fastest;
  *  - the caller (PyTorch) owns and allocates every buffer, including saved-for-backward tensors and
  *    scratch; sizes come from tfnas_cell_ws();
@@ -88,9 +88,9 @@ typedef struct TfnasCellDesc {
     float eps;                /* BatchNorm eps (1e-5)                               [in] */
     int32_t mode;             /* TFNAS_MODE_CELL / _STEM / _HEAD                    [in] */
     int32_t Hi, Wi;           /* stem mode: height / width of the NCHW input image  [in] */
-    int32_t stor;             /* storage of the [pixels][M] stream tensors E, D, dZ, dEh: 0 = fp32 (the parity mode),
-                                 1 = bf16 (throughput mode: BASELINE configs[1] "bf16"; statistics, accumulation and every
-                                 other tensor stay fp32; tfnas_cell_ws sizes the four buffers accordingly)        [in] */
+    int32_t stor;             /* must be 0 (fp32 storage of the [pixels][M] stream tensors E, D, dZ, dEh).  Rounds 1-3 had a
+                                 second build that kept these four tensors in bf16 (stor = 1); it measured 0.99-1.04x of the
+                                 fp32 iteration pair (the step is not bound by HBM bytes) and was removed.          [in] */
     int32_t xg;               /* 1: every group has its OWN input -- x and dx are [G][N*H*W][ic] (group g at g*N*H*W*ic) and
                                  dx[g] receives group g's gradient only; 0: one shared input, dx summed over the groups.
                                  Requires og = 1.                                                                  [in] */
@@ -132,11 +132,6 @@ typedef struct TfnasCellWs {
 } TfnasCellWs;
 
 int tfnas_abi_version(void);
-
-/* 1 when this build of the library accepts TfnasCellDesc.stor = 1 (bf16 storage of E, D, dZ, dEh).  The product library
- * libtfnas_hip.so is built without it (the runtime branches cost the fp32 path 2.3 %); libtfnas_hip_bf16.so -- same sources,
- * same ABI -- with it. */
-int tfnas_has_bf16_storage(void);
 
 /* ---- cross-rank BatchNorm statistics ("sync-stats") -------------------------------------------------------------------------
  * Data-parallel runs normalise with PER-RANK batch statistics by default (what un-synced DDP / nn.DataParallel do; the

@@ -76,6 +76,9 @@ def test_error_codes(lib):
     assert lib.tfnas_cell_plan(C.byref(_desc(stride=3))) == -1
     assert lib.tfnas_cell_plan(C.byref(_desc(ks=(3, 7)))) == -1
     assert lib.tfnas_cell_plan(C.byref(_desc(ses=(0, 22)))) == -1    # SE width must be a multiple of 4
+    st = _desc()
+    st.stor = 1
+    assert lib.tfnas_cell_plan(C.byref(st)) == -1                    # fp32 storage only (the bf16-storage build was removed)
     bad = _desc()
     bad.G = 9
     assert lib.tfnas_cell_plan(C.byref(bad)) == -3
@@ -96,10 +99,7 @@ def test_error_codes(lib):
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from tfnas_amd import _lib
-    monkeypatch.setattr(_lib, '_libs', {})
+    monkeypatch.setattr(_lib, '_lib_handle', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
-    monkeypatch.setattr(_lib, 'LIB_PATH_BF16', str(tmp_path / 'nope16.so'))
     with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
         _lib.lib()
-    with pytest.raises(RuntimeError, match='no CPU/PyTorch fallback'):
-        _lib.lib(bf16=True)

@@ -107,14 +107,6 @@ extern "C" int tfnas_set_stats_sync(tfnas_stats_sync_fn fn, void* user, int worl
 
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
 
-extern "C" int tfnas_has_bf16_storage(void) {
-#ifdef TFNAS_NO_BF16
-    return 0;
-#else
-    return 1;
-#endif
-}
-
 extern "C" uint64_t tfnas_sizeof(int which) {
     switch (which) {
         case 0: return sizeof(TfnasGroup);
@@ -143,14 +135,7 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         return TFNAS_EINVAL;
     }
     if (d->mode == TFNAS_MODE_HEAD && d->G != 1) return TFNAS_EINVAL;
-    if (d->stor != 0 && d->stor != 1) return TFNAS_EINVAL;
-#ifdef TFNAS_NO_BF16
-    if (d->stor) return TFNAS_EINVAL;         // this build has the bf16-storage branches compiled out (see Makefile)
-#endif
-#ifdef TFNAS_ONLY_BF16
-    if (!d->stor) return TFNAS_EINVAL;        // ... and this one the fp32-storage branches: MixedOP cells with stor = 1 only
-#endif
-    if (d->stor && d->mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;      // bf16 storage: MixedOP cells only (stems / head keep fp32)
+    if (d->stor != 0) return TFNAS_EINVAL;     // fp32 storage only (the bf16-storage build of rounds 1-3 was removed: tfnas_hip.h)
     if (d->N < 1 || d->H < 1 || d->W < 1 || d->oc < 4 || (d->oc & 3)) return TFNAS_EINVAL;
     if (d->oc > 1024) return TFNAS_EINVAL;
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
@@ -202,10 +187,9 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     memset(ws, 0, sizeof(*ws));
     const uint64_t P = (uint64_t)d->N * d->H * d->W, Po = (uint64_t)d->N * d->Ho * d->Wo;
     const uint64_t M = d->M, N = d->N, SE = d->SE, G = d->G, oc = d->oc;
-    // the four stream tensors: elements P*M / Po*M, stored fp32 or bf16 (two per float slot)
-    const uint64_t sdiv = d->stor ? 2 : 1;
-    ws->E = (P * M + sdiv - 1) / sdiv;
-    ws->D = (Po * M + sdiv - 1) / sdiv;
+    // the four stream tensors: P*M / Po*M fp32 elements
+    ws->E = P * M;
+    ws->D = Po * M;
     ws->Pr = G * Po * oc;
     ws->off_pooled = 0;
     ws->off_gate = N * M;
@@ -216,8 +200,8 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_stats3 = 4 * M;
     ws->stats = 4 * M + 2 * G * oc;
     ws->out = (d->og ? G : 1) * Po * oc;
-    ws->dZ = (Po * M + sdiv - 1) / sdiv;
-    ws->dEh = (P * M + sdiv - 1) / sdiv;
+    ws->dZ = Po * M;
+    ws->dEh = P * M;
     ws->off_dgate = 0;
     ws->off_dpooled = N * M;
     ws->off_dgl = 2 * N * M;

@@ -641,15 +641,10 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
         for (int i = 0; i < 2; ++i) prow[i] = rt * 128 + wrow + 16 * i + lr;
         auto la = [&](int c, int i, int kl) -> f32x4 {
             const int pc = min(prow[i], P - 1), k = min(k0 + kl, klim_a - 4);
-            if (TFNAS_STOR(d.stor)) {        // bf16 dEh and fp32 x are different load widths
-                if (is_x) return ld4(x + (size_t)pc * ic + k);
-                return ldS4_raw(dEh, (size_t)pc * M + aoff + k, 1);
-            }
             return ld4((is_x ? x : dEh) + (size_t)pc * ld_a + aoff + k);       // wave-uniform select, one unconditional load
         };
         auto xa = [&](f32x4 r, int c, int i, int kl) -> f32x4 {
-            const f32x4 v = (TFNAS_STOR(d.stor) && !is_x) ? ldS4_fin(r, 1) : r;
-            return (prow[i] < P && k0 + kl < klim_a) ? v : zero4();
+            return (prow[i] < P && k0 + kl < klim_a) ? r : zero4();
         };
         auto lb = [&](int c, int kl, int n) -> RawWS {
             const int kc = min(k0 + kl, klim_b - 1), col = min(n0 + n, ic - 4);

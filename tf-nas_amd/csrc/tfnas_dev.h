@@ -73,90 +73,19 @@ __device__ __forceinline__ f32x4 ld4_nt(const float* p) {
 }
 __device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 #endif
-// ----------------------------------------------------------------------------- bf16 storage of the stream tensors
-// TfnasCellDesc.stor = 1: E, D, dZ, dEh hold bf16 (round-to-nearest-even on store, exact widening on load); `idx` below is an
-// ELEMENT index, `base` the tensor's base pointer (typed float* throughout the library).  stor is wave-uniform: the branch is
-// a scalar one and the fp32 path executes exactly the instructions it did before.
-typedef unsigned tf_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 bf16x4_widen(uint2 u) {
-    f32x4 r;
-    r.x = __uint_as_float(u.x << 16);
-    r.y = __uint_as_float(u.x & 0xffff0000u);
-    r.z = __uint_as_float(u.y << 16);
-    r.w = __uint_as_float(u.y & 0xffff0000u);
-    return r;
-}
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;          // (NaN payloads are not preserved; none occur here)
-}
-// gfx950 has the packed conversion in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): 2 instructions per quad where the
-// integer sequence above took ~20 -- the stores of the bf16 mode sit in VALU-bound kernels
-typedef float tf_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 tf_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint2 bf16x4_narrow(f32x4 v) {
-#ifdef TFNAS_BF16_SW
-    uint2 r0;
-    r0.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
-    r0.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
-    return r0;
-#endif
-    const tf_f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-    const tf_bf16x2 a = __builtin_convertvector(lo, tf_bf16x2), b = __builtin_convertvector(hi, tf_bf16x2);
-    uint2 r;
-    r.x = *reinterpret_cast<const unsigned*>(&a);
-    r.y = *reinterpret_cast<const unsigned*>(&b);
-    return r;
-}
-#if defined(TFNAS_NO_BF16)           /* the product library: bf16 branches compiled out */
+// ----------------------------------------------------------------------------- stream-tensor accessors
+// E, D, dZ, dEh are fp32.  (Rounds 1-3 carried a second build with bf16 storage of these four tensors, TfnasCellDesc.stor = 1:
+// it ended at 0.99-1.04x of the fp32 iteration pair -- the step is bound by launch structure and by LDS / VALU work, not by HBM
+// bytes -- and was removed; `stor` must be 0, the parameter below remains in the signatures of the loaders.)  `idx` is an
+// ELEMENT index, `base` the tensor's base pointer.
 #define TFNAS_STOR(s) 0
-#elif defined(TFNAS_ONLY_BF16)       /* the bf16 library: fp32-storage branches compiled out (its plan accepts stor = 1 only).
-                                        As wave-uniform RUNTIME branches around every load / store of the stream tensors they
-                                        broke the kernels' load pipelines into dozens of basic blocks: 1.2-1.75x slower per
-                                        kernel than the fp32 build although the bytes halve */
-#define TFNAS_STOR(s) 1
-#else
-#define TFNAS_STOR(s) (s)
-#endif
-__device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int stor) {
-    if (TFNAS_STOR(stor)) return bf16x4_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx));
-    return ld4(base + idx);
-}
-// two-phase form for loaders that must not touch the loaded registers before the MFMAs (gemm_core.h): _raw only issues the
-// load (bf16: the 8 raw bytes travel in .x/.y), _fin widens
-__device__ __forceinline__ f32x4 ldS4_raw(const float* base, size_t idx, int stor) {
-    if (TFNAS_STOR(stor)) {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
-        f32x4 r = {__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
-        return r;
-    }
-    return ld4(base + idx);
-}
-__device__ __forceinline__ f32x4 ldS4_fin(f32x4 raw, int stor) {
-    if (TFNAS_STOR(stor)) return bf16x4_widen(make_uint2(__float_as_uint(raw.x), __float_as_uint(raw.y)));
-    return raw;
-}
-__device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int stor) {
-    if (TFNAS_STOR(stor)) {
-        const tf_u32x2 u = __builtin_nontemporal_load(
-            reinterpret_cast<const tf_u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx));
-        return bf16x4_widen(make_uint2(u.x, u.y));
-    }
-    return ld4_nt(base + idx);
-}
-__device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int stor) {
-    if (TFNAS_STOR(stor)) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = bf16x4_narrow(v);
-    else st4(base + idx, v);
-}
-__device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int stor) {
-    if (TFNAS_STOR(stor)) {
-        const uint2 n = bf16x4_narrow(v);
-        tf_u32x2 u = {n.x, n.y};
-        __builtin_nontemporal_store(u, reinterpret_cast<tf_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx));
-    } else {
-        st4_nt(base + idx, v);
-    }
-}
+__device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int) { return ld4(base + idx); }
+// two-phase form for loaders that must not touch the loaded registers before the MFMAs (gemm_core.h)
+__device__ __forceinline__ f32x4 ldS4_raw(const float* base, size_t idx, int) { return ld4(base + idx); }
+__device__ __forceinline__ f32x4 ldS4_fin(f32x4 raw, int) { return raw; }
+__device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int) { return ld4_nt(base + idx); }
+__device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int) { st4(base + idx, v); }
+__device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int) { st4_nt(base + idx, v); }
 
 // agent-scope (write-through) store of a value another workgroup of the same launch reads back (gemm_core.h: tail_reduce_cols)
 __device__ __forceinline__ void st_coherent(float* p, float v) {

@@ -350,11 +350,11 @@ static int wgrad_tn_mode() {
 }
 bool wgrad_tn_enabled() { return wgrad_tn_mode() > 0; }
 
-// true when the launch was taken (fp32 storage only; the bf16-storage build keeps the LDS-tiled kernels)
+// true when the launch was taken
 bool launch_project_wgrad_tn(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D, const float* gate,
                              const double* stats2, const double* stats3, const double* red3, const float* wmix, float* part,
                              hipStream_t s, int* rc) {
-    if (!wgrad_tn_enabled() || TFNAS_STOR(d.stor) || (d.oc & 3) || d.oc < 4) return false;
+    if (!wgrad_tn_enabled() || (d.oc & 3) || d.oc < 4) return false;
     const int Po = d.N * d.Ho * d.Wo;
     if (Po >= (1 << 24)) return false;
     int mcp_max = 0;
@@ -390,7 +390,7 @@ bool launch_project_wgrad_tn(const TfnasCellDesc& d, const float* dout, const fl
 
 bool launch_expand_wgrad_tn(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1, const float* x,
                             float* part, hipStream_t s, int* rc) {
-    if (!wgrad_tn_enabled() || TFNAS_STOR(d.stor) || d.mode != TFNAS_MODE_CELL || (d.ic & 3)) return false;
+    if (!wgrad_tn_enabled() || d.mode != TFNAS_MODE_CELL || (d.ic & 3)) return false;
     const int P = d.N * d.H * d.W;
     int mcp_max = 0;
     size_t out_size = 0;

@@ -13,7 +13,6 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFNAS_LIB') or os.path.join(_HERE, 'libtfnas_hip.so')     # (TFNAS_LIB: an experiment build of the same ABI)
-LIB_PATH_BF16 = os.path.join(_HERE, 'libtfnas_hip_bf16.so')     # same sources + the bf16-storage mode (csrc/Makefile)
 
 MAX_GROUPS, MAX_SINK, MAX_CELLS = 8, 4, 32
 ACT = {'relu': 0, 'swish': 1}
@@ -69,7 +68,6 @@ _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _PROTOS = {
     'tfnas_abi_version': (C.c_int, []),
-    'tfnas_has_bf16_storage': (C.c_int, []),
     'tfnas_shutdown': (C.c_int, []),
     'tfnas_sizeof': (C.c_uint64, [C.c_int]),
     'tfnas_cell_plan': (C.c_int, [C.POINTER(TfnasCellDesc)]),
@@ -111,16 +109,15 @@ _PROTOS = {
     'tfnas_sink_bwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, _P, _P, C.c_uint64, C.POINTER(_P), _P, _P, _P, _P]),
 }
 
-_libs = {}
+_lib_handle = None
 
 
-def lib(bf16=False):
-    """Load (once) and return the shared library; raises RuntimeError when it is absent.  ``bf16=True``: the build for
-    TfnasCellDesc.stor = 1 (bf16 storage of the stream tensors; MixedOP cells only -- each library is compiled for ONE storage
-    mode, stems / head / fp32 cells always go through the default one)."""
-    l = _libs.get(bool(bf16))
+def lib():
+    """Load (once) and return the shared library; raises RuntimeError when it is absent."""
+    global _lib_handle
+    l = _lib_handle
     if l is None:
-        path = LIB_PATH_BF16 if bf16 else LIB_PATH
+        path = LIB_PATH
         if not os.path.exists(path):
             raise RuntimeError(
                 'tfnas_amd: HIP extension %s is missing -- run `python -c "import __graft_entry__ as g; g.build()"` '
@@ -134,9 +131,7 @@ def lib(bf16=False):
         for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs, TfnasBnAffine)):
             if l.tfnas_sizeof(which) != C.sizeof(st):
                 raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
-        if bool(l.tfnas_has_bf16_storage()) != bool(bf16):
-            raise RuntimeError('tfnas_amd: %s was built %s bf16 storage' % (path, 'without' if bf16 else 'with'))
-        _libs[bool(bf16)] = l
+        _lib_handle = l
     return l
 
 

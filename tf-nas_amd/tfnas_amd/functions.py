@@ -23,10 +23,6 @@ EFREE = os.environ.get('TFNAS_EFREE', '1') != '0'
 # The library also supports stride 1 and ic = 40, where the row-streaming kernels on a materialised E are still faster;
 # TFNAS_EFREE_STRIDE1=1 takes E-free wherever it is supported (tests).
 EFREE_STRIDE1 = os.environ.get('TFNAS_EFREE_STRIDE1', '0') == '1'
-# storage of the [pixels][M] stream tensors (E, D, dZ, dEh) on the per-cell route: 'fp32' (parity mode) or 'bf16'
-# (throughput mode, TfnasCellDesc.stor = 1; BASELINE configs[1]).  tfnas_amd.search.SearchState(model, storage=...) sets the
-# same switch for the path level.
-STORAGE = os.environ.get('TFNAS_STORAGE', 'fp32')
 
 
 def _stream(dev):
@@ -91,22 +87,20 @@ class CellPlan:
         return ps
 
     def desc(self, N, H, W):
-        stor = int(STORAGE == 'bf16' and self.mode == _lib.MODE_CELL)
-        key = (N, H, W, stor)
+        key = (N, H, W)
         hit = self._desc_cache.get(key)
         if hit is None:
             d = TfnasCellDesc()
             d.N, d.H, d.W, d.ic, d.oc, d.stride = N, H, W, self.ic, self.oc, self.stride
             d.mode = self.mode
-            d.stor = stor
             if self.mode == _lib.MODE_STEM:            # (H, W) given = image size; plan derives the conv output size
                 d.Hi, d.Wi = H, W
             d.act, d.has_res, d.G, d.need_wgrad, d.eps = _lib.ACT[self.act], self.has_res, len(self.blocks), 0, BN_EPS
             for g, b in enumerate(self.blocks):
                 d.g[g].mc, d.g[g].k, d.g[g].se = b.mid_channels, b.kernel_size, b.se_channels
-            check(_lib.lib(bool(stor)).tfnas_cell_plan(C.byref(d)), 'tfnas_cell_plan')
+            check(_lib.lib().tfnas_cell_plan(C.byref(d)), 'tfnas_cell_plan')
             ws = TfnasCellWs()
-            check(_lib.lib(bool(stor)).tfnas_cell_ws(C.byref(d), C.byref(ws)), 'tfnas_cell_ws')
+            check(_lib.lib().tfnas_cell_ws(C.byref(d), C.byref(ws)), 'tfnas_cell_ws')
             hit = (d, ws)
             self._desc_cache[key] = hit
         return hit
@@ -138,7 +132,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
     # cells never materialise the expanded tensor -- the depthwise kernels recompute it from x
     efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and not any(ctx.needs_input_grad[3:])
-             and bool(_lib.lib(bool(d.stor)).tfnas_efree_supported(C.byref(d))))
+             and bool(_lib.lib().tfnas_efree_supported(C.byref(d))))
     E = None if efree else torch.empty(ws.E, device=dev, dtype=torch.float32)
     D = torch.empty(ws.D, device=dev, dtype=torch.float32)
     Pr = torch.empty(ws.Pr, device=dev, dtype=torch.float32)
@@ -149,7 +143,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     if wmix is not None:
         wmix = wmix.contiguous()
     with _on(dev):
-        check(_lib.lib(bool(d.stor)).tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+        check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                            ptr(stats), ptr(part), ptr(out), _stream(dev)), 'tfnas_mixedop_fwd')
     ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
     if MixedOpFn.fwd_sink is not None:
@@ -180,7 +174,7 @@ def _cell_backward(ctx, dout, want_dx):
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
     _same_device(dev, [douth], 'the output gradient')
     with _on(dev):
-        check(_lib.lib(bool(d.stor)).tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+        check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                            ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
                                            ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream(dev)), 'tfnas_mixedop_bwd')
     d.need_wgrad = 0

@@ -204,14 +204,11 @@ class MixedStage(nn.Module):
         self.register_parameter('betas', nn.Parameter(torch.zeros((self.num_res))))
 
 
-# Network.forward on the path level when it can (GPU model, fp32 storage, tfnas_amd.search.USE_PATHS): TFNAS_MODULE_PATHS=0
+# Network.forward on the path level when it can (GPU model, tfnas_amd.search.USE_PATHS): TFNAS_MODULE_PATHS=0
 # keeps the per-cell route (one autograd node per MixedOP: what the stage-by-stage tests hook into)
 MODULE_PATHS = os.environ.get('TFNAS_MODULE_PATHS', '1') != '0'
 
 
-def FN_STORAGE():
-    from . import functions
-    return functions.STORAGE
 
 
 class Network(nn.Module):
@@ -404,7 +401,7 @@ class Network(nn.Module):
 
     def _use_paths(self, x):
         from . import search
-        if not (MODULE_PATHS and search.USE_PATHS and x.is_cuda and FN_STORAGE() == 'fp32'):
+        if not (MODULE_PATHS and search.USE_PATHS and x.is_cuda):
             return False
         p = self.first_stem.conv.weight
         return p.is_cuda and p.is_leaf and p.device == x.device

@@ -107,12 +107,9 @@ class _Slot:
 
 
 class PathRunner:
-    def __init__(self, model, weights=None, storage='fp32'):
-        if storage not in ('fp32', 'bf16'):
-            raise ValueError("storage must be 'fp32' or 'bf16'")
-        self.storage = storage                      # of the [pixels][M] stream tensors (TfnasCellDesc.stor)
+    def __init__(self, model, weights=None):
         self.model = model
-        self.lib = _lib.lib(storage == 'bf16')
+        self.lib = _lib.lib()
         self.cells = model.cells()
         self.stages = model.stages()
         self.weights = weights                      # WeightArena or None (then need_wgrad paths are refused)
@@ -179,7 +176,6 @@ class PathRunner:
         d = TfnasCellDesc()
         d.N, d.H, d.W, d.ic, d.oc, d.stride = N, H, W, cell.in_channels, cell.out_channels, cell.stride
         d.mode = _lib.MODE_CELL
-        d.stor = int(self.storage == 'bf16')
         d.act, d.G, d.need_wgrad, d.eps = _lib.ACT[cell.act_func], len(blocks), 0, BN_EPS
         d.has_res = int(cell.in_channels == cell.out_channels and cell.stride == 1)
         for g, b in enumerate(blocks):

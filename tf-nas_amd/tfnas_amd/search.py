@@ -43,11 +43,8 @@ def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-
 class SearchState:
     """Caches the parameter lists the reference rebuilds from named_parameters() six times per step."""
 
-    def __init__(self, model, storage='fp32'):
-        """``storage``: 'fp32' (parity mode) or 'bf16' -- the [pixels][M] stream tensors E, D, dZ, dEh of every cell are kept
-        in bf16 (fp32 statistics, accumulation, weights, gradients): the throughput mode of BASELINE configs[1]."""
+    def __init__(self, model):
         self.model = model
-        self.storage = storage
         self.weights = model.weight_parameters()
         self.arch = model.arch_parameters()
         self._mode = None
@@ -82,7 +79,7 @@ class SearchState:
         if self.runner is not None:
             self.runner.close()
         self.arena = WeightArena(self.model)
-        self.runner = PathRunner(self.model, self.arena, self.storage)
+        self.runner = PathRunner(self.model, self.arena)
         if len(self._wgrad_streams) == 2:
             self.runner.wgrad_streams = self._wgrad_map()
         self._op_params, self._op_span, self._mom_bound = {}, {}, None

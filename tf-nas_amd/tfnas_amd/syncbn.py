@@ -28,12 +28,7 @@ class _Raw:
 
 
 def _libs():
-    out = [_lib.lib()]
-    try:
-        out.append(_lib.lib(True))
-    except Exception:
-        pass
-    return out
+    return [_lib.lib()]
 
 
 def enable(group=None):

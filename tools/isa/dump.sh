@@ -6,4 +6,4 @@
 #            python tools/isa/loop_hist.py   /tmp/gemm.s "k_project_fwd<4, 1>" 40  (opcode histogram of the loop)
 #            python tools/isa/regs.py        /tmp/gemm.s "project_fwd|expand"      (VGPRs and scratch bytes per kernel)
 cd "$(dirname "$0")/../../tf-nas_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics \
-  -ffp-contract=fast -I../../include -I. -DTFNAS_NO_BF16 $EXTRA -S --cuda-device-only -o "$2" "$1.hip"
+  -ffp-contract=fast -I../../include -I. $EXTRA -S --cuda-device-only -o "$2" "$1.hip"
