@@ -58,12 +58,12 @@ def cell_table(B):
     return rows
 
 
-def family_algorithmic(fam, B):
+def family_algorithmic(fam, B, mode=None):
     """Algorithmic (flops, bytes) summed over the KERNEL launches one iteration pair makes of kernel family `fam`,
     plus that launch count.  alpha-step: all 8 candidates of the 18 cells (backward kernels skip the first cell,
     whose input needs no gradient); w-step: 2 paths x 18 cells x 1 candidate x 2 w-steps (expected value over
     uniform candidate choice).  Depthwise families launch one kernel per kernel size present (2 in the soft
-    mode).  fp32 = 4 B/element.  Only families that can dominate are modelled; others return None."""
+    mode).  mode = 'soft' / 'sampled': only the alpha-step launches / only the w-step launches (stems included).  fp32 = 4 B/element.  Only families that can dominate are modelled; others return None."""
     from tfnas_amd import geometry as g
     fl = by = 0.0
     n = 0
@@ -74,6 +74,8 @@ def family_algorithmic(fam, B):
         Mavg = Msoft / 8.0
         for M, launches in ((Msoft, 1), (Mavg, 4)):          # soft launch once, sampled launch 4x per pair
             G = 8 if launches == 1 else 1
+            if (mode == 'soft' and launches != 1) or (mode == 'sampled' and launches == 1):
+                continue
             if launches == 1 and backward and ci == 0:
                 continue                                       # pruned: first cell of the alpha-step
             kernels = launches * (2 if (fam.startswith('k_dw_') and launches == 1) else 1)
@@ -127,7 +129,9 @@ def family_algorithmic(fam, B):
             'k_se_pool<bwd>': (8.0 * P * M, 4.0 * 2 * P * M, 2),
             'k_project_wgrad': (2.0 * P * M * oc, 4.0 * (P * M + 2 * P * oc), 2),
             'k_dw_wgrad': (2.0 * P * M * 9.0, 4.0 * 3 * P * M, 2)}.get(fam)
-    if stem is not None:
+    if stem is not None and mode != 'soft':
+        if mode == 'sampled' and stem[2] == 3:
+            stem = (stem[0], stem[1], 2)                      # (the alpha-step's stem forward is not a sampled launch)
         fl += stem[0] * stem[2]
         by += stem[1] * stem[2]
         n += stem[2]
@@ -375,6 +379,9 @@ def run_gpu(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     dom = collect()[dominant]
+    dom_soft = (C.c_uint64(0), C.c_double(0.0))
+    _lib.check(lib.tfnas_prof_last_split(names.index(dominant), C.byref(dom_soft[0]), C.byref(dom_soft[1])), 'tfnas_prof_last_split')
+    dom_soft = (dom_soft[0].value, dom_soft[1].value)
     lib.tfnas_prof_enable(0)
     _require_finite(model, 'the timed region')
 
@@ -467,6 +474,20 @@ def run_gpu(args):
                             frac=round(gbs / PEAK_HBM_GBS, 4))
             if roof['frac'] > 1.0:
                 raise SystemExit('bench.py: byte/flop model of %s gives frac %.2f > 1 -- the model is wrong' % (dominant, roof['frac']))
+            # the same kernels at two sizes: alpha-step launches (all 8 candidates of a cell, one queue) and w-step launches (one
+            # candidate, four queues side by side) -- each against its own algorithmic bytes / flops
+            by_mode = {}
+            for mname, (cnt_m, ms_m) in (('soft', dom_soft), ('sampled', (dom[0] - dom_soft[0], dom[1] - dom_soft[1]))):
+                am = family_algorithmic(dominant, B, mname)
+                if am is None or cnt_m <= 0 or am[2] <= 0:
+                    continue
+                a_ms_ = ms_m / cnt_m
+                tf_m, gb_m = am[0] / am[2] / (a_ms_ * 1e-3) / 1e12, am[1] / am[2] / (a_ms_ * 1e-3) / 1e9
+                by_mode[mname] = dict(launches_timed=cnt_m, avg_launch_ms=round(a_ms_, 4), gbs=round(gb_m, 1), tflops=round(tf_m, 2),
+                                      frac=round(max(tf_m / PEAK_FP32_MFMA_TF, gb_m / PEAK_HBM_GBS), 4),
+                                      alg_bytes_per_launch=am[1] / am[2])
+            if dom_soft[0] > 0 and by_mode:
+                roof['by_mode'] = by_mode
             roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 4), launches_timed=dom[0],
                         alg_flops_per_launch=fl / nl, alg_bytes_per_launch=by / nl, traffic=None,
                         share_of_step=round(dom[1] / args.steps / ms_per_step, 3))

@@ -405,6 +405,9 @@ int tfnas_prof_enable(unsigned mask);
 int tfnas_prof_count(void);
 const char *tfnas_prof_name(int id);
 int tfnas_prof_collect(int id, uint64_t *launches, double *total_ms);
+/* of the launches the LAST tfnas_prof_collect(id) returned: those that covered all candidates of a cell (alpha-step launches of
+ * the depthwise families), count and summed ms -- the same kernels run at two very different sizes in the two step kinds */
+int tfnas_prof_last_split(int id, uint64_t *soft_launches, double *soft_ms);
 
 #ifdef __cplusplus
 }

@@ -708,7 +708,7 @@ static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const flo
         const int tile = gm.L0 * gm.L1 * gm.CC > 2048 ? gm.L0 * gm.L1 * gm.CC : 2048;
         const size_t shm = (size_t)(tile + kk * kk * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
-        ProfScope _prof(TK_DW_FWD, s);
+        ProfScope _prof(TK_DW_FWD, s, d.G > 2);
         if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
         DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
             hipLaunchKernelGGL((k_dw_fwd<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, E, x, stats1, D, part, gm, tail);
@@ -737,7 +737,7 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
                            sizeof(float);
         if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
         dim3 grid(gx, chunks);
-        ProfScope _prof(TK_DW_BWD_DATA, s);
+        ProfScope _prof(TK_DW_BWD_DATA, s, d.G > 2);
         DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
             hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2,
                                red2, E, x, stats1, dEh, part, gm, tail);

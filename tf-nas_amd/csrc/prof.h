@@ -13,8 +13,9 @@ struct ProfScope {
     int id;
     hipStream_t s;
     hipEvent_t e0;
-    bool on;
-    ProfScope(int id, hipStream_t s);
+    bool on, soft;
+    // soft: the launch covers all candidates of a cell (alpha-step); reported separately by tfnas_prof_last_split
+    ProfScope(int id, hipStream_t s, bool soft = false);
     void stop();          // record the end event now (idempotent); the destructor calls it
     ~ProfScope() { stop(); }
 };

@@ -106,6 +106,7 @@ _PROTOS = {
     'tfnas_prof_count': (C.c_int, []),
     'tfnas_prof_name': (C.c_char_p, [C.c_int]),
     'tfnas_prof_collect': (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    'tfnas_prof_last_split': (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     'tfnas_sink_bwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, _P, _P, C.c_uint64, C.POINTER(_P), _P, _P, _P, _P]),
 }
 
