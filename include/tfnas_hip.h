@@ -397,6 +397,17 @@ int tfnas_arch_adam_project(int n, float *const *p, const float *const *g, const
                             float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
                             float grad_scale, float *norm_out, void *stream);
 
+/* ---- lazy join of the weight-gradient side stream (derived-network training step) ------------------------------------------
+ * tfnas_mixedop_bwd / tfnas_mbconv_bwd run their weight-gradient kernels on a library-owned side stream per caller stream and
+ * join it before they return.  With tfnas_set_lazy_join(1), tfnas_mbconv_bwd returns WITHOUT joining: the weight gradients of a
+ * block then overlap with the data-gradient chain of the blocks below it.  The caller must (1) keep every buffer passed to the
+ * call alive until the side stream is done with it (PyTorch: tensor.record_stream on tfnas_side_stream(stream)), and
+ * (2) call tfnas_side_join(stream) before anything on `stream` reads the weight gradients (the optimizer step).
+ * (train_eval.py:228-252 has no such notion: one stream; this is scheduling only, the results are bit-identical.) */
+int tfnas_set_lazy_join(int on);
+int tfnas_side_stream(void *stream, void **side);   /* *side = the side stream paired with `stream` (NULL: TFNAS_WGRAD_STREAM=0) */
+int tfnas_side_join(void *stream);
+
 /* ---- optional diagnostics (used by bench.py for the `roofline` object) --------------------------------------
  * Per-kernel-family timing with HIP events recorded on the launch stream.  tfnas_prof_enable(mask) turns the
  * families whose bit is set on (0 = off, the default); tfnas_prof_collect() waits for the recorded events of

@@ -114,6 +114,41 @@ def test_derived_network_train_step_and_eval_match_oracle():
         assert torch.equal(m2(x.cuda()), em)
 
 
+def test_in_place_gradients_and_lazy_join_are_bit_identical_to_the_plain_route(monkeypatch):
+    """model_eval.RetrainState: gradients written straight into the arena by the kernels (no temporaries, no AccumulateGrad
+    adds) and ONE join of the weight-gradient stream per step instead of one per block are scheduling / plumbing only: three
+    training steps give bit-identical parameters, momentum and running statistics with either switch off."""
+    from tfnas_amd import model_eval as me
+    arch, mc = _arch()
+
+    def run(direct, lazy):
+        monkeypatch.setattr(me, 'DIRECT_GRADS', direct)
+        monkeypatch.setattr(me, 'LAZY_JOIN', lazy)
+        torch.manual_seed(5)
+        m = me.Network(50, arch, mc, None, 0.0, 0.2).cuda()
+        opt = torch.optim.SGD(m.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+        crit = me.CrossEntropyLabelSmooth(50, 0.1)
+        gen = torch.Generator().manual_seed(11)
+        blocks = [m.second_stem] + [b for st in m._stages() for b in st]
+        for _ in range(3):
+            x = torch.randn(16, 3, 128, 128, generator=gen).cuda()
+            y = torch.randint(0, 50, (16,), generator=gen).cuda()
+            for b in blocks:
+                b.drop_u = torch.rand(16, generator=gen)
+            me.train_step(m, x, y, crit, opt, 5.0)
+        torch.cuda.synchronize()
+        out = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        out.update({'mom%d' % i: opt.state[p]['momentum_buffer'].detach().cpu().clone() for i, p in enumerate(m.parameters())})
+        return out
+
+    base = run(False, False)
+    for direct, lazy in ((True, False), (False, True), (True, True)):
+        other = run(direct, lazy)
+        assert base.keys() == other.keys()
+        for k in base:
+            assert torch.equal(base[k], other[k]), (direct, lazy, k)
+
+
 def test_retrain_schedule_checkpoints_and_resume(tmp_path):
     """run_retrain (train_eval.py:118-226): config + checkpoints with the reference's keys, resume continues the schedule; the
     derived network is built from a search checkpoint like `--model_path` does."""

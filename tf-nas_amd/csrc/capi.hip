@@ -82,6 +82,27 @@ struct SideJoinGuard {
     }
 };
 
+// Lazy join (derived-network training step): tfnas_mbconv_bwd leaves its weight-gradient kernels running on the side stream
+// when this is on; the caller keeps every buffer they read alive (torch: record_stream on the side stream's handle) and joins
+// once before it consumes the gradients (tfnas_side_join).
+static int g_lazy_join = 0;
+extern "C" int tfnas_set_lazy_join(int on) {
+    g_lazy_join = on ? 1 : 0;
+    return 0;
+}
+extern "C" int tfnas_side_stream(void* stream, void** side) {
+    if (!side) return TFNAS_ENULL;
+    *side = nullptr;
+    if (!side_enabled()) return 0;
+    SideCtx* c = side_for(S(stream));
+    if (c) *side = (void*)c->side;
+    return 0;
+}
+extern "C" int tfnas_side_join(void* stream) {
+    if (!side_enabled()) return 0;
+    return side_join(side_for(S(stream)), S(stream));
+}
+
 extern "C" int tfnas_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_side_mu);
     for (SideCtx* c : g_side) {
@@ -486,6 +507,10 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
     b.drop_scale = drop_scale;
     b.dout_s = dout_s;
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
+    if (g_lazy_join) {              // the caller joins later (tfnas_side_join)
+        guard.joined = true;
+        return 0;
+    }
     return guard.join();
 }
 

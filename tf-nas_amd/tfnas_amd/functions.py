@@ -415,6 +415,52 @@ def _bn_struct(bns, training, grads=None):
     return a
 
 
+# Training-step context of the derived network (model_eval.RetrainState.begin / step):
+#   direct: every parameter's .grad is a view of the flat gradient arena, zeroed at the start of the step, and every parameter
+#           is used once per step -- the kernels then write the gradients in place and the Function returns None for them
+#           (no temporaries, no AccumulateGrad add per parameter: ~200 tiny launches per step);
+#   lazy:   tfnas_mbconv_bwd leaves the weight-gradient kernels on the side stream (tfnas_set_lazy_join); the tensors they read
+#           are handed to the caching allocator with record_stream(side), the step joins once before the optimizer kernel.
+_RETRAIN = {'direct': False, 'lazy': False}
+_side_streams = {}
+
+
+def retrain_context(direct, lazy):
+    _RETRAIN['direct'], _RETRAIN['lazy'] = bool(direct), bool(lazy)
+    _lib.lib().tfnas_set_lazy_join(int(bool(lazy)))
+
+
+def _side_stream(dev):
+    """torch handle of the library's weight-gradient side stream paired with the current stream of `dev` (None: disabled)."""
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        h = C.c_void_p(None)
+        with torch.cuda.device(dev):
+            check(_lib.lib().tfnas_side_stream(C.c_void_p(cur.cuda_stream), C.byref(h)), 'tfnas_side_stream')
+        st = _side_streams[key] = torch.cuda.ExternalStream(h.value, device=dev) if h.value else False
+    return st or None
+
+
+def retrain_join(dev):
+    with torch.cuda.device(dev):
+        check(_lib.lib().tfnas_side_join(_stream(dev)), 'tfnas_side_join')
+
+
+def _direct_targets(params):
+    """The .grad views to write into, or None when a parameter has no (contiguous fp32) .grad yet."""
+    if not _RETRAIN['direct']:
+        return None
+    out = []
+    for p in params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+            return None
+        out.append(g)
+    return out
+
+
 class MBConvAffineFn(torch.autograd.Function):
     """One MBInvertedResBlock of the derived network (or the stem cell: plan.mode == MODE_STEM) with affine BatchNorm.
     inputs: plan, x, drop_scale [N] or None, bns (three nn.BatchNorm2d), training flag, n_conv, *params where
@@ -451,6 +497,7 @@ class MBConvAffineFn(torch.autograd.Function):
                 if m is not None and m.num_batches_tracked is not None:
                     m.num_batches_tracked += 1
         ctx.plan, ctx.shape, ctx.bns, ctx.training, ctx.n_conv = plan, (N, H, W), bns, training, n_conv
+        ctx.direct = _direct_targets(params) if training else None
         ctx.save_for_backward(xh, ds, E, D, Pr, fsmall, stats, *params)
         return out.permute(0, 3, 1, 2)
 
@@ -462,8 +509,12 @@ class MBConvAffineFn(torch.autograd.Function):
         d, ws = plan.desc(N, H, W)
         dev = xh.device
         conv, bnp = params[:n_conv], params[n_conv:]
-        gconv = [torch.empty_like(p) for p in conv]
-        gbn = [torch.zeros_like(p) for p in bnp]
+        direct = ctx.direct
+        if direct is not None:
+            gconv, gbn = direct[:n_conv], direct[n_conv:]
+        else:
+            gconv = [torch.empty_like(p) for p in conv]
+            gbn = [torch.zeros_like(p) for p in bnp]
         plan.bind(d, conv, gconv)
         douth = _nhwc(dout)
         want_dx = ctx.needs_input_grad[1] and plan.mode != _lib.MODE_STEM
@@ -481,7 +532,18 @@ class MBConvAffineFn(torch.autograd.Function):
                                               ptr(stats), ptr(douth), ptr(dout_s), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
                                               ptr(part), ptr(dx), ptr(dxp), _stream(dev)), 'tfnas_mbconv_bwd')
         d.need_wgrad = 0
-        return (None, None if dx is None else dx.permute(0, 3, 1, 2), None, None, None, None) + tuple(gconv) + tuple(gbn)
+        if _RETRAIN['lazy'] and direct is None:
+            retrain_join(dev)               # gradient temporaries go back to autograd: they must be complete on this stream
+        elif _RETRAIN['lazy']:
+            side = _side_stream(dev)
+            if side is not None:            # the weight-gradient kernels still read these when this function returns
+                for t in (xh, ds, E, D, Pr, fsmall, stats, douth, dout_s, dZ, dEh, bsmall, red, part):
+                    if t is not None:
+                        t.record_stream(side)
+        dxo = None if dx is None else dx.permute(0, 3, 1, 2)
+        if direct is not None:
+            return (None, dxo, None, None, None, None) + (None,) * len(params)
+        return (None, dxo, None, None, None, None) + tuple(gconv) + tuple(gbn)
 
 
 class HeadAffineFn(torch.autograd.Function):

@@ -9,6 +9,8 @@ head -- runs on the HIP kernels of the search path (``tfnas_mbconv_fwd/bwd``, ``
 folded into the per-channel statistics tables, csrc/bn_affine.hip); dropout, the classifier GEMM and the loss are torch ops.
 ``CrossEntropyLabelSmooth`` and ``train_step`` / ``validate`` restate train_eval.py:72-85, 228-293.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -189,6 +191,12 @@ class CrossEntropyLabelSmooth(nn.Module):
         return F.cross_entropy(xs, targets, label_smoothing=self.epsilon)
 
 
+# TFNAS_RETRAIN_DIRECT=0: the blocks return gradient temporaries and autograd adds them into the arena (one launch per parameter);
+# TFNAS_RETRAIN_LAZY=0: every block joins its weight-gradient kernels before it returns.
+DIRECT_GRADS = os.environ.get('TFNAS_RETRAIN_DIRECT', '1') != '0'
+LAZY_JOIN = os.environ.get('TFNAS_RETRAIN_LAZY', '1') != '0'
+
+
 class RetrainState:
     """Flat weight / gradient / momentum arenas of the derived network (path.WeightArena) + the fused step tail of the search
     path: ``.grad`` of every parameter is a view into ONE gradient buffer (autograd accumulates in place), so a data-parallel
@@ -231,17 +239,28 @@ class RetrainState:
         self._bound = opt
 
     def begin(self):
-        """Zero the gradient arena (one memset) and make every .grad a view of it."""
+        """Zero the gradient arena (one memset), make every .grad a view of it, and switch the blocks' backward to writing the
+        gradients in place with a lazily joined weight-gradient stream (functions.retrain_context)."""
+        from . import functions
         a = self.arena
         a.g.zero_()
         for p in a.params:
             if p.grad is None or p.grad.data_ptr() != a.grad_ptr(p):
                 p.grad = a.grad_view(p)
+        functions.retrain_context(DIRECT_GRADS, LAZY_JOIN)
+
+    def end(self):
+        """Join the weight-gradient stream and leave the training-step context (also on an error path)."""
+        from . import functions
+        if functions._RETRAIN['lazy']:
+            functions.retrain_join(self.arena.device)
+        functions.retrain_context(False, False)
 
     def step(self, opt, grad_clip, group=None):
         import ctypes as C
         import torch.distributed as dist
         a = self.arena
+        self.end()                                       # the gradients are complete on the current stream from here on
         self._bind_momentum(opt)
         hp = opt.param_groups[0]
         scale = 1.0
@@ -275,11 +294,16 @@ def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None
             st = RetrainState(model)
             object.__setattr__(model, '_retrain_state', st)         # (not a submodule / buffer: stays out of state_dict)
         st.begin()
-    logits = model(x)
-    loss = criterion(logits, target)
-    if st is None:
-        optimizer.zero_grad()
-    loss.backward()
+    try:
+        logits = model(x)
+        loss = criterion(logits, target)
+        if st is None:
+            optimizer.zero_grad()
+        loss.backward()
+    except BaseException:
+        if st is not None:
+            st.end()
+        raise
     if st is not None:
         st.step(optimizer, grad_clip, group)
         return loss.detach(), logits.detach()

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export CF_SAMPLED_ONLY=1
+export CF_SAMPLED_ONLY=${CF_SAMPLED_ONLY:-1}
 rocprofv3 -L > $OUT/counters.txt 2>&1
 run() { timeout 300 rocprofv3 --kernel-trace --pmc $2 -d $OUT/$1 --output-format csv -- python $REPO/tools/cell_family.py "${@:3}" > $OUT/$1.log 2>&1 || true; }
 run p1 "FETCH_SIZE GRBM_GUI_ACTIVE" "$@"
