@@ -554,6 +554,43 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
     }
 }
 
+// tall tables (statistics partials: 200..1024 rows of 10^2..10^3 columns) with 16-byte loads: QN column quads x (256/QN) row
+// lanes per workgroup, 8 float4 loads in flight per thread -- the scalar k_reduce_rows<4> moved 16-byte pieces per row
+template <int QN>
+__global__ __launch_bounds__(256) void k_reduce_rows_q(const float* __restrict__ part, int nb, int ncols, size_t stride,
+                                                       double* __restrict__ out_d, float* __restrict__ out_f,
+                                                       size_t in_stride, size_t out_stride) {
+    constexpr int RL = 256 / QN;
+    __shared__ double buf[RL][4 * QN + 2];
+    part += blockIdx.y * in_stride;
+    if (out_d) out_d += blockIdx.y * out_stride;
+    if (out_f) out_f += blockIdx.y * out_stride;
+    const int tid = threadIdx.x, cq = tid % QN, rl = tid / QN;
+    const int c = (blockIdx.x * QN + cq) * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c < ncols) {
+        for (int b = rl; b < nb; b += 8 * RL) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (b + RL * u < nb) ? ld4(part + (size_t)(b + RL * u) * stride + c) : zero4();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s[j] += (((double)v[0][j] + (double)v[1][j]) + ((double)v[2][j] + (double)v[3][j])) +
+                        (((double)v[4][j] + (double)v[5][j]) + ((double)v[6][j] + (double)v[7][j]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) buf[rl][4 * cq + j] = s[j];
+    __syncthreads();
+    if (tid < 4 * QN && blockIdx.x * 4 * QN + tid < ncols) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) t += buf[r][tid];
+        if (out_d) out_d[blockIdx.x * 4 * QN + tid] = t;
+        if (out_f) out_f[blockIdx.x * 4 * QN + tid] = (float)t;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_reduce_rows_wide(const float* __restrict__ part, int nb, int ncols, size_t stride,
                                                           double* __restrict__ out_d, float* __restrict__ out_f,
                                                           size_t in_stride, size_t out_stride) {
@@ -592,30 +629,35 @@ __global__ __launch_bounds__(256) void k_reduce_rows_wide(const float* __restric
 __global__ __launch_bounds__(256) void k_reduce_bn1(TfnasCellDesc d, const float* __restrict__ part, int nb,
                                                     const double* __restrict__ stats1, double* __restrict__ red1,
                                                     float* __restrict__ cb1) {
-    constexpr int CL = 8, RL = 32;
-    __shared__ double buf[RL][CL + 1];
+    // 4 column quads (16 columns = 8 channels) x 64 row lanes, float4 loads (2 * M is a multiple of 64 floats, rows are 16-byte
+    // aligned): the scalar version moved 32-byte pieces per row
+    constexpr int QN = 4, CL = 4 * QN, RL = 256 / QN;
+    __shared__ double buf[RL][CL + 2];
     __shared__ double tot[CL];
-    const int tid = threadIdx.x, cl = tid % CL, rl = tid / CL;
-    const int ncols = 2 * d.M, c = blockIdx.x * CL + cl;
+    const int tid = threadIdx.x, cq = tid % QN, rl = tid / QN;
+    const int ncols = 2 * d.M, c = (blockIdx.x * QN + cq) * 4;
     const size_t stride = (size_t)ncols;
-    double s = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < ncols) {
-        for (int b = rl; b < nb; b += 16 * RL) {
-            float v[16];
+        for (int b = rl; b < nb; b += 8 * RL) {
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (b + RL * u < nb) ? part[(size_t)(b + RL * u) * stride + c] : 0.f;
+            for (int u = 0; u < 8; ++u) v[u] = (b + RL * u < nb) ? ld4(part + (size_t)(b + RL * u) * stride + c) : zero4();
 #pragma unroll
-            for (int u = 0; u < 16; u += 4) s += ((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3]);
+            for (int j = 0; j < 4; ++j)
+                s[j] += (((double)v[0][j] + (double)v[1][j]) + ((double)v[2][j] + (double)v[3][j])) +
+                        (((double)v[4][j] + (double)v[5][j]) + ((double)v[6][j] + (double)v[7][j]));
         }
     }
-    buf[rl][cl] = s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) buf[rl][4 * cq + j] = s[j];
     __syncthreads();
-    if (rl == 0) {
+    if (tid < CL) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < RL; ++r) t += buf[r][cl];
-        tot[cl] = t;
-        if (c < ncols) red1[c] = t;
+        for (int r = 0; r < RL; ++r) t += buf[r][tid];
+        tot[tid] = t;
+        if (blockIdx.x * CL + tid < ncols) red1[blockIdx.x * CL + tid] = t;
     }
     __syncthreads();
     if (tid < CL / 2) {
@@ -640,10 +682,14 @@ __global__ __launch_bounds__(256) void k_reduce_bn1(TfnasCellDesc d, const float
 int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const double* stats1, double* red1, float* cb1,
                       hipStream_t s) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
-    hipLaunchKernelGGL(k_reduce_bn1, dim3(cdiv(2 * d.M, 8)), dim3(256), 0, s, d, part, nb, stats1, red1, cb1);
+    hipLaunchKernelGGL(k_reduce_bn1, dim3(cdiv(2 * d.M, 16)), dim3(256), 0, s, d, part, nb, stats1, red1, cb1);
     return (int)hipGetLastError();
 }
 
+static int rq_mode() {
+    static const int v = getenv("TFNAS_REDUCE_Q") ? atoi(getenv("TFNAS_REDUCE_Q")) : 4;     // 0: the scalar kernels
+    return v;
+}
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s, int nbatch, size_t in_stride, size_t out_stride) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
@@ -652,6 +698,12 @@ int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, doub
     if (al4 && nb <= 128 && ncols >= 1024)
         hipLaunchKernelGGL(k_reduce_rows_wide, dim3(cdiv(ncols, 128), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d,
                            out_f, in_stride, out_stride);
+    else if (al4 && nb > 64 && rq_mode() == 8)
+        hipLaunchKernelGGL(k_reduce_rows_q<8>, dim3(cdiv(ncols, 32), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
+                           in_stride, out_stride);
+    else if (al4 && nb > 64 && rq_mode() == 4)
+        hipLaunchKernelGGL(k_reduce_rows_q<4>, dim3(cdiv(ncols, 16), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
+                           in_stride, out_stride);
     else if (ncols <= 2048 && nb > 256)
         hipLaunchKernelGGL(k_reduce_rows<4>, dim3(cdiv(ncols, 4), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
                            in_stride, out_stride);
