@@ -42,9 +42,18 @@ __device__ __forceinline__ void expand_b_load(ExpandB<KQ>& B, const float* __res
 // tile[pix * CS + ch], pix < npix, ch < 32:  OUT = 0/1: act_OUT(BN1(E)),  OUT = 2: BN1(E) (normalised, no activation);
 // exact zeros for pixels outside the image (locate(pix, off) == false).  All 256 threads must call it (wave-uniform
 // loop; __ballot carries the validity of the 16 pixels of an M-tile to the lanes that hold their results).
+// (expand_tile_to: the pixel's 32 floats go to dst(pix) instead of tile + pix * CS -- the row-streaming kernels' LDS ring)
+template <int KQ, int OUT, class FLoc, class FDst>
+__device__ __forceinline__ void expand_tile_to(int npix, const float* __restrict__ x, const ExpandB<KQ>& B, FLoc locate,
+                                               FDst dst);
 template <int KQ, int OUT, class FLoc>
 __device__ __forceinline__ void expand_tile(float* tile, int npix, int CS, const float* __restrict__ x,
                                             const ExpandB<KQ>& B, FLoc locate) {
+    expand_tile_to<KQ, OUT>(npix, x, B, locate, [&](int pix) { return tile + pix * CS; });
+}
+template <int KQ, int OUT, class FLoc, class FDst>
+__device__ __forceinline__ void expand_tile_to(int npix, const float* __restrict__ x, const ExpandB<KQ>& B, FLoc locate,
+                                               FDst dst) {
     // NB M-tiles per round: all their x loads are issued before the first MFMA (the loads come from L2 / Infinity
     // Cache, ~1-2 us each; one tile at a time would serialise that latency 5-7 times per spatial tile)
     constexpr int NB = KQ <= 4 ? 4 : (KQ <= 6 ? 3 : 2);
@@ -91,8 +100,9 @@ __device__ __forceinline__ void expand_tile(float* tile, int npix, int CS, const
                             v1 = act_f<(OUT == 2 ? 0 : OUT)>(v1);
                         }
                     }
-                    tile[pix * CS + n] = v0;
-                    tile[pix * CS + 16 + n] = v1;
+                    float* o = dst(pix);
+                    o[n] = v0;
+                    o[16 + n] = v1;
                 }
             }
         }
