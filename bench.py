@@ -129,10 +129,8 @@ def family_algorithmic(fam, B, mode=None):
             'k_se_pool<bwd>': (8.0 * P * M, 4.0 * 2 * P * M, 2),
             'k_project_wgrad': (2.0 * P * M * oc, 4.0 * (P * M + 2 * P * oc), 2),
             'k_dw_wgrad': (2.0 * P * M * 9.0, 4.0 * 3 * P * M, 2)}.get(fam)
-    if stem is not None and mode != 'soft':
-        if mode == 'sampled' and stem[2] == 3:
-            stem = (stem[0], stem[1], 2)                      # (the alpha-step's stem forward is not a sampled launch)
-        fl += stem[0] * stem[2]
+    if stem is not None and mode != 'soft':                   # (the stems are one-candidate launches in both step kinds: the
+        fl += stem[0] * stem[2]                               #  profiler's split, G > 2, files all of them under 'sampled')
         by += stem[1] * stem[2]
         n += stem[2]
     return fl, by, n

@@ -132,3 +132,21 @@ def test_parsing_known_answers_and_lut_builder_key_set(tmp_path):
     lut_builder.save_lat_lookup(small, p)
     back = load_lat_lookup(p)
     assert back['base'] == 1.5 and back[keys[0]][8] == small[keys[0]][8]
+
+
+def test_bench_byte_model_splits_into_step_kinds():
+    """bench.py's algorithmic (flops, bytes, launches) of a kernel family = its alpha-step launches + its w-step launches
+    (what roofline.by_mode divides the two event-time buckets by); weight-gradient families have no alpha-step part."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for fam in ('k_dw_bwd_data', 'k_dw_fwd', 'k_project_fwd', 'k_expand_dgrad', 'k_se_pool<bwd>', 'k_dw_wgrad'):
+        tot, soft, samp = (bench.family_algorithmic(fam, 128, m) for m in (None, 'soft', 'sampled'))
+        for i in range(3):
+            assert abs(tot[i] - (soft[i] + samp[i])) <= 1e-9 * max(1.0, abs(tot[i])), (fam, i, tot, soft, samp)
+        assert samp[2] > 0
+        assert (soft[2] == 0) == (fam == 'k_dw_wgrad')
+    assert bench.family_algorithmic('no_such_family', 128) is None
