@@ -408,6 +408,27 @@ int tfnas_set_lazy_join(int on);
 int tfnas_side_stream(void *stream, void **side);   /* *side = the side stream paired with `stream` (NULL: TFNAS_WGRAD_STREAM=0) */
 int tfnas_side_join(void *stream);
 
+/* ---- arithmetic of the 1x1-convolution GEMMs --------------------------------------------------------------------------------
+ * The reference runs its pointwise convolutions in fp32 (models/layers.py:463-478, 528-534; the search is never AMP).  gfx950
+ * executes fp32 MFMA at 1/16 of its bf16 MFMA rate, so the row-tiled GEMMs (expand / project forward and data gradients) split
+ * every fp32 operand EXACTLY into three bf16 planes and accumulate the six products that matter in fp32 (csrc/gemm_x3.h):
+ *   TFNAS_GEMM_X3   (6, default)  six bf16 MFMAs per element pair, error <= 2^-23 |a||b| per product: fp32-level accuracy
+ *   TFNAS_GEMM_F32  (0)           v_mfma_f32_16x16x4_f32, bit-identical to an fmaf chain
+ *   TFNAS_GEMM_X2   (3)           three products (error ~2^-16)
+ *   TFNAS_GEMM_BF16 (1)           plain bf16 operands, fp32 accumulation (the reduced-precision mode of the derived network's
+ *                                 training step; train_eval_amp.py:176-180 in the reference)
+ * Process-wide; the environment variable TFNAS_GEMM = x3 | f32 | x2 | bf16 sets the initial value.  Returns TFNAS_EINVAL for
+ * any other mode.  tfnas_gemm_mode() returns the current one. */
+#define TFNAS_GEMM_F32 0
+#define TFNAS_GEMM_BF16 1
+#define TFNAS_GEMM_X2 3
+#define TFNAS_GEMM_X3 6
+/* OR-ed into the mode: every row-tiled GEMM launch uses it.  Without the flag the library keeps the fp32 loop where the split
+ * loop measured slower (the data-gradient GEMMs of one-candidate launches and of the large images). */
+#define TFNAS_GEMM_EVERYWHERE 0x100
+int tfnas_set_gemm_mode(int mode);
+int tfnas_gemm_mode(void);
+
 /* ---- optional diagnostics (used by bench.py for the `roofline` object) --------------------------------------
  * Per-kernel-family timing with HIP events recorded on the launch stream.  tfnas_prof_enable(mask) turns the
  * families whose bit is set on (0 = off, the default); tfnas_prof_collect() waits for the recorded events of

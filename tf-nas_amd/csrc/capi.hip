@@ -127,6 +127,8 @@ extern "C" int tfnas_set_stats_sync(tfnas_stats_sync_fn fn, void* user, int worl
 }
 
 extern "C" int tfnas_abi_version(void) { return TFNAS_ABI_VERSION; }
+extern "C" int tfnas_set_gemm_mode(int mode) { return set_gemm_mode(mode); }
+extern "C" int tfnas_gemm_mode(void) { return gemm_mode(); }
 
 extern "C" uint64_t tfnas_sizeof(int which) {
     switch (which) {

@@ -26,7 +26,10 @@ struct GT {
     static constexpr int LDA = BM + 16;
     static constexpr int LDB = (BN % 32 == 16) ? BN : BN + 16;
     static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
-    static constexpr int LDS_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+    // (the split-bf16 loop of gemm_x3.h stages B as three bf16 planes of 32 k: 2 buffers x 3 planes x NT column tiles x
+    //  1056 bytes in the transposed-read layout, x 1024 in the K-contiguous one)
+    static constexpr int X3_FLOATS = 1584 * NT;
+    static constexpr int LDS_FLOATS = 2 * (A_FLOATS + B_FLOATS) > X3_FLOATS ? 2 * (A_FLOATS + B_FLOATS) : X3_FLOATS;
     static constexpr int B_ITEMS = BN * 4;                 // float4 items of one B tile
     static constexpr int B_ITERS = (B_ITEMS + 255) / 256;
 };

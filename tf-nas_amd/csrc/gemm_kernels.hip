@@ -5,7 +5,9 @@
 //   expand  = inverted_bottleneck.conv (layers.py:463-478)   project = point_linear.conv (layers.py:528-534)
 // and the autograd backward of those convolutions + BatchNorm2d(affine=False, batch stats).
 #include <stdlib.h>
+#include <string.h>
 #include "gemm_core.h"
+#include "gemm_x3.h"
 #include "kernels.h"
 #include "prof.h"
 
@@ -39,6 +41,17 @@ __device__ __forceinline__ f32x4 stem_patch4(const float* __restrict__ img, cons
 #ifndef TFNAS_LB_SMALL
 #define TFNAS_LB_SMALL 4
 #endif
+// the split-bf16 loop (MM != 0) keeps two chunks of raw operands and three A planes in registers: one resident workgroup less
+#ifndef TFNAS_LB_X3_BIG
+#define TFNAS_LB_X3_BIG 2
+#endif
+#ifndef TFNAS_LB_X3_SMALL
+#define TFNAS_LB_X3_SMALL 3
+#endif
+// (heavy: k_project_dgrad, whose BN3-backward transform keeps 40 table values per chunk pair live: 217-249 registers)
+constexpr int gemm_lb(int nt, int mm, bool heavy = false) {
+    return mm == 0 ? (nt >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) : ((nt >= 5 || heavy) ? TFNAS_LB_X3_BIG : TFNAS_LB_X3_SMALL);
+}
 
 // -DTFNAS_WG_TIMING (tools/wg_timeline.py): per-workgroup wall-clock stamps (100 MHz s_memrealtime) of the weight-gradient
 // GEMMs: [wg][0..3] = start, after prologue, after K loop, end
@@ -63,8 +76,8 @@ struct RawWS { f32x4 w; float s; };      // a weight quad and its row scale
 // ============================================================================ expand forward
 // E[p][off_g + m] = sum_c x[p][c] * w_expand_g[m][c]      for all groups in one launch
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
-template <int NT, bool STEM>
-__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
+template <int NT, bool STEM, int MM>
+__global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
                                                     float* __restrict__ E, float* __restrict__ part,
                                                     unsigned* __restrict__ tail_cnt, double* __restrict__ stats1) {
     using T = GT<NT>;
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
             return (n0 + n < mc && c * 16 + kl < ic) ? r : zero4();
         };
         PreNone pre;
-        gemm_mainloop_adirect<NT, true>(pre, la, xa, lb, xb, nchunks, acc, lds);
+        gemm_adirect<NT, true, MM>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < P && n0 + lc < mcp) stS4_nt(E, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -138,8 +151,8 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
 // epilogue: stats3[g][o] (BN3 batch statistics)
 // (launch bounds: the 7-tile variant otherwise takes 149 VGPRs + 56 AGPRs = 2 waves/SIMD, measured 1.5 resident; capping
 //  it at 168 registers buys the third wave: -17 % on the 112-channel cells)
-template <int NT, int ACT>
-__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
+template <int NT, int ACT, int MM>
+__global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
                                                      float* __restrict__ part, int nsplit, float* __restrict__ prp,
@@ -215,15 +228,15 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
         };
         auto lb = [&](int c, int n, int kl) -> f32x4 {
             const int o = n0 + n, k = (cb + c) * 16 + kl;
-            if (!w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, false) : zero4();
+            if (MM == 0 && !w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, k, mc, false) : zero4();
             return ld4(w + (size_t)min(o, oc - 1) * mc + min(k, mc - 4));          // mc % 4 == 0: k < mc <=> k + 3 < mc
         };
         auto xb = [&](f32x4 r, int c, int n, int kl) -> f32x4 {
-            if (!w_al) return r;
+            if (MM == 0 && !w_al) return r;
             return (n0 + n < oc && (cb + c) * 16 + kl < mc) ? r : zero4();
         };
         PreNone pre;
-        gemm_mainloop_adirect<NT, true>(pre, la, xa, lb, xb, nchunks, acc, lds);
+        gemm_adirect<NT, true, MM>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < oc) st4(dst + ((size_t)g * Po + p) * oc + n0 + lc, v);
@@ -317,10 +330,40 @@ __device__ __forceinline__ f32x4 bn3_dp(const Bn3Tab& t, int o, f32x4 dout, f32x
     return r;
 }
 
+// Folded form for k_project_dgrad: one float4 (mean, a3, a3 b3, rstd c3 a3) per output channel,
+//   dP = a3 dOut - a3 b3 - (Pr - mean) (rstd c3 a3)      (the form k_project_wgrad keeps in registers)
+// -- one ds_read_b128 and three VALU operations per element instead of five table reads and six operations.
+__device__ __forceinline__ void bn3_fold_fill(f32x4* tab, int ocp, const TfnasCellDesc& d, int g, const double* stats3,
+                                              const double* red3, const float* wmix) {
+    const int Po = d.N * d.Ho * d.Wo;
+    const double inv = 1.0 / (double)Po;
+    const float wg = wmix ? wmix[g] : 1.f;
+    for (int o = threadIdx.x; o < ocp; o += blockDim.x) {
+        f32x4 t = zero4();
+        if (o < d.oc) {
+            const float2 c = bn_consts(stats3 + 2 * ((size_t)g * d.oc + o), inv, d.eps);
+            const float a3 = wg * c.y;
+            const float b3 = (float)(red3[2 * ((size_t)g * d.oc + o) + 0] * inv);
+            const float c3 = (float)(red3[2 * ((size_t)g * d.oc + o) + 1] * inv);
+            t = f32x4{c.x, a3, a3 * b3, c.y * c3 * a3};
+        }
+        tab[o] = t;
+    }
+}
+__device__ __forceinline__ f32x4 bn3_fold_dp(const f32x4* tab, int o, f32x4 dout, f32x4 pr) {
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = tab[o + j];
+        r[j] = (t.y * dout[j] - t.z) - (pr[j] - t.x) * t.w;
+    }
+    return r;
+}
+
 // ============================================================================ project dgrad
 // dZ[p][off_g + c] = sum_o dP_g[p][o] * w_proj_g[o][c]
-template <int NT>
-__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
+template <int NT, int MM>
+__global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
                                                        const double* __restrict__ red3,
@@ -342,7 +385,8 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
     const int nrt = (Po + 127) >> 7, nchunks = ocp >> 4;
     const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
 
-    const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
+    f32x4* tab = reinterpret_cast<f32x4*>(lds + T::LDS_FLOATS);
+    bn3_fold_fill(tab, ocp, d, g, stats3, red3, wmix);
     __syncthreads();
     if (d.og) dout += (size_t)g * Po * oc;                 // every group has its own output gradient
 
@@ -368,20 +412,20 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
         };
         auto xa = [&](Raw2 r, int c, int i, int kl) -> f32x4 {
             const int o = c * 16 + kl;
-            const f32x4 v = bn3_dp(tab, min(o, oc - 4), r.a, r.b);
+            const f32x4 v = bn3_fold_dp(tab, min(o, oc - 4), r.a, r.b);
             return (rok[i] && o < oc) ? v : zero4();
         };
         auto lb = [&](int c, int kl, int n) -> f32x4 {
             const int o = c * 16 + kl;
-            if (!w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, false) : zero4();
+            if (MM == 0 && !w_al) return (o < oc) ? ld4_guard(w + (size_t)o * mc, n0 + n, mc, false) : zero4();
             return ld4(w + (size_t)min(o, oc - 1) * mc + min(n0 + n, mc - 4));
         };
         auto xb = [&](f32x4 r, int c, int kl, int n) -> f32x4 {
-            if (!w_al) return r;
+            if (MM == 0 && !w_al) return r;
             return (c * 16 + kl < oc && n0 + n < mc) ? r : zero4();
         };
         PreNone pre;
-        gemm_mainloop_adirect<NT, false>(pre, la, xa, lb, xb, nchunks, acc, lds);
+        gemm_adirect<NT, false, MM>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow;
             if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
@@ -556,8 +600,8 @@ __device__ __forceinline__ f32x4 sink_add(f32x4 v, float w, f32x4 g) {
 // is -G; b is added in the epilogue.  G | b come from k_expand_gram ([ic+4][ic] floats, row ic = b).
 // K (up to 6912) is split over blockIdx.z when the output grid alone cannot fill the chip (7x7 / 14x14 cells: 49..196 row
 // tiles): split z writes its partial tile to dxp[z] and k_dx_reduce adds them (and b, and the residual term).
-template <int NT>
-__global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+template <int NT, int MM>
+__global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ x, const float* __restrict__ cb1,
                                                       const float* __restrict__ gram, const float* __restrict__ dout,
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
@@ -658,7 +702,7 @@ __global__ __launch_bounds__(256, NT >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL) void 
             const f32x4 v = is_x ? -r.w : splat4(r.s) * r.w;
             return (n0 + n < ic && k0 + kl < klim_b) ? v : zero4();
         };
-        gemm_mainloop_adirect<NT, false>(pre, la, xa, lb, xb, nchunks, acc, lds);
+        gemm_adirect<NT, false, MM>(pre, la, xa, lb, xb, nchunks, acc, lds);
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow, c = n0 + lc;
             if (p < P && c < ic) {
@@ -882,6 +926,37 @@ static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channe
         case 7: { constexpr int NT = 7; __VA_ARGS__; } break; \
         default: return TFNAS_EINVAL;                         \
     }
+// Arithmetic of the row-tiled 1x1-convolution GEMMs (gemm_x3.h): 6 = split-bf16 with six products per element pair (fp32-level
+// accuracy on the bf16 matrix pipe; the default), 0 = v_mfma_f32_16x16x4_f32, 3 = split-bf16 keeping the 2^-16 terms,
+// 1 = plain bf16.  TFNAS_GEMM = x3 | f32 | x2 | bf16 sets the process default; tfnas_set_gemm_mode overrides it.
+static int g_gemm_mode = -1;
+static int g_gemm_everywhere = 0;      // TFNAS_GEMM_EVERYWHERE: no per-launch shape policy (tests compare every mode with the oracle)
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("TFNAS_GEMM");
+        int m = 6;
+        if (e && !strcmp(e, "f32")) m = 0;
+        else if (e && !strcmp(e, "x2")) m = 3;
+        else if (e && !strcmp(e, "bf16")) m = 1;
+        g_gemm_mode = m;
+    }
+    return g_gemm_mode;
+}
+int set_gemm_mode(int m) {
+    const int base = m & ~TFNAS_GEMM_EVERYWHERE;
+    if (base != 0 && base != 1 && base != 3 && base != 6) return TFNAS_EINVAL;
+    g_gemm_mode = base;
+    g_gemm_everywhere = (m & TFNAS_GEMM_EVERYWHERE) ? 1 : 0;
+    return 0;
+}
+#define DISPATCH_MM(...) DISPATCH_MM_(gemm_mode(), __VA_ARGS__)
+#define DISPATCH_MM_(mode, ...)                               \
+    switch (mode) {                                    \
+        case 0: { constexpr int MM = 0; __VA_ARGS__; } break; \
+        case 1: { constexpr int MM = 1; __VA_ARGS__; } break; \
+        case 3: { constexpr int MM = 3; __VA_ARGS__; } break; \
+        default: { constexpr int MM = 6; __VA_ARGS__; } break; \
+    }
 #define DISPATCH_ACT(act, ...)                                                        \
     if ((act) == TFNAS_ACT_RELU) { constexpr int ACT = TFNAS_ACT_RELU; __VA_ARGS__; } \
     else { constexpr int ACT = TFNAS_ACT_SWISH; __VA_ARGS__; }
@@ -925,7 +1000,32 @@ static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30, int slo
     }
     return best;
 }
-static inline int gemm_slots(int nt) { return 256 * (nt >= 5 ? TFNAS_LB_BIG : TFNAS_LB_SMALL); }
+int gemm_mode();
+static inline int gemm_slots(int nt, int mode = -1) { return 256 * gemm_lb(nt, mode < 0 ? gemm_mode() : mode); }
+// ragged mid widths (mc % 4 != 0 after the elasticity re-masking): the split-bf16 instantiations only have the aligned weight
+// loaders (the guarded ones cost ~50 registers, i.e. a resident workgroup), such launches keep the fp32 loop
+static inline int gemm_mode_for(const TfnasCellDesc& d) {
+    for (int g = 0; g < d.G; ++g)
+        if (d.g[g].mc & 3) return 0;
+    return gemm_mode();
+}
+// The data-gradient GEMMs gain little from the bf16 pipe (their K loops are bound by the BN3-backward transform / the chunk ->
+// group bookkeeping and, with one candidate or large images, by bytes): measured per cell at B = 128 (tools/r4_cf.sh), split-bf16
+// vs fp32 MFMA: all-candidate launches of the 14x14 / 7x7 cells 0.94-0.98x, 28x28 up to 1.19x, one-candidate launches 0.9-1.8x.
+// They keep the fp32 loop except where they won; TFNAS_GEMM_DGRAD=1 / 0 forces the choice.
+static inline int gemm_mode_dgrad(const TfnasCellDesc& d) {
+    static const int force = getenv("TFNAS_GEMM_DGRAD") ? atoi(getenv("TFNAS_GEMM_DGRAD")) : -1;
+    const int m = gemm_mode_for(d);
+    if (m == 0 || force == 1 || g_gemm_everywhere) return m;
+    if (force == 0) return 0;
+    if (m == 1) return m;                                  // plain bf16 is a reduced-precision MODE, not a policy: everywhere
+    return (d.G > 1 && d.Ho * d.Wo <= 196) ? m : 0;
+}
+static inline int gemm_mode_fwd(const TfnasCellDesc& d, int hw) {
+    static const int maxhw = getenv("TFNAS_X3_MAXHW_FWD") ? atoi(getenv("TFNAS_X3_MAXHW_FWD")) : (1 << 30);
+    const int m = gemm_mode_for(d);
+    return (m == 1 || hw <= maxhw || g_gemm_everywhere) ? m : 0;
+}
 
 // Column-tile width of the GEMMs whose N extent is the mid channels of EVERY group (tiles cannot straddle groups): the
 // candidate that pads the group widths least (72 | 144 -> 5 x 16: 960 columns for 864, where 4 x 16 needs 1280 and
@@ -959,18 +1059,21 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     const int nt = d.mode == TFNAS_MODE_STEM ? (d.g[0].mcp <= 32 ? 2 : 4) : pick_nt_groups(d);
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt)), tiles);
+    const int mm = gemm_mode_fwd(d, d.H * d.W);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt, mm)), tiles);
     unsigned* tcnt = (tail_enabled() && tiles <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
-    if (d.mode == TFNAS_MODE_STEM) {
-        if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
-        else hipLaunchKernelGGL((k_expand_fwd<4, true>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
-    } else {
-        switch (nt) {
-            case 5: hipLaunchKernelGGL((k_expand_fwd<5, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
-            case 7: hipLaunchKernelGGL((k_expand_fwd<7, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
-            default: hipLaunchKernelGGL((k_expand_fwd<4, false>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+    DISPATCH_MM_(mm, {
+        if (d.mode == TFNAS_MODE_STEM) {
+            if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
+            else hipLaunchKernelGGL((k_expand_fwd<4, true, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
+        } else {
+            switch (nt) {
+                case 5: hipLaunchKernelGGL((k_expand_fwd<5, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+                case 7: hipLaunchKernelGGL((k_expand_fwd<7, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+                default: hipLaunchKernelGGL((k_expand_fwd<4, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+            }
         }
-    }
+    })
     _prof.stop();
     if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
@@ -979,7 +1082,7 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
                        float* Pr, double* stats3, float* part, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_FWD, s);
-    const int nt = pick_nt(d.oc, kNtSmall, 6);
+    const int nt = pick_nt(d.oc, kNtSmall, 6), mm = gemm_mode_fwd(d, d.Ho * d.Wo);
     int mcp_max = 0;
     for (int g = 0; g < d.G; ++g) mcp_max = d.g[g].mcp > mcp_max ? d.g[g].mcp : mcp_max;
     const int tiles = cdiv(d.oc, 16 * nt);
@@ -1001,11 +1104,11 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         float* prp = part;
         float* part2 = part + (size_t)(nsplit - 1) * d.G * Po * d.oc;
         dim3 grid(nrt, tiles, d.G * nsplit);
-        DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
+        DISPATCH_MM_(mm, DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
             const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-            hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp,
+            hipLaunchKernelGGL((k_project_fwd<NT, ACT, MM>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp,
                                (unsigned*)nullptr, (double*)nullptr);
-        }))
+        })))
         int gx2 = cdiv(Po, 64);
         if (gx2 > 256) gx2 = 256;
         const int rps = cdiv(Po, gx2);
@@ -1014,13 +1117,13 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         _prof.stop();
         return launch_reduce_rows(part2, gx2, ncols2, (size_t)ncols2, stats3, nullptr, s);
     }
-    dim3 grid(row_blocks(Po, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt)), tiles, d.G);
+    dim3 grid(row_blocks(Po, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt, mm)), tiles, d.G);
     unsigned* tcnt = (tail_enabled() && tiles * d.G <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
-    DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
+    DISPATCH_MM_(mm, DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-        hipLaunchKernelGGL((k_project_fwd<NT, ACT>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, 1,
+        hipLaunchKernelGGL((k_project_fwd<NT, ACT, MM>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, 1,
                            (float*)nullptr, tcnt, stats3);
-    }))
+    })))
     _prof.stop();
     if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
@@ -1029,14 +1132,14 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
                          const double* red3, const float* wmix, float* dZ, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_DGRAD, s);
-    const int nt = pick_nt_groups(d);
+    const int nt = pick_nt_groups(d), mm = gemm_mode_dgrad(d);
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
-    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(nt)), tiles);
-    DISPATCH_NT(nt, {
-        const size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
-        hipLaunchKernelGGL(k_project_dgrad<NT>, grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
-    })
+    dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(nt, mm)), tiles);
+    DISPATCH_MM_(mm, DISPATCH_NT(nt, {
+        const size_t shm = (GT<NT>::LDS_FLOATS + 4 * ((d.oc + 15) & ~15)) * sizeof(float);
+        hipLaunchKernelGGL((k_project_dgrad<NT, MM>), grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
+    }))
     return (int)hipGetLastError();
 }
 
@@ -1153,11 +1256,12 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
     const int tiles = cdiv(d.ic, 16 * nt);
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
     const int ng = d.xg ? d.G : 1;
-    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit * ng, 1u << 30, gemm_slots(nt), 4096), tiles, nsplit * ng);
-    DISPATCH_NT(nt, {
-        hipLaunchKernelGGL(k_expand_dgrad<NT>, grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit,
+    const int mm = gemm_mode_dgrad(d);
+    dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit * ng, 1u << 30, gemm_slots(nt, mm), 4096), tiles, nsplit * ng);
+    DISPATCH_MM_(mm, DISPATCH_NT(nt, {
+        hipLaunchKernelGGL((k_expand_dgrad<NT, MM>), grid, dim3(256), 0, s, d, dEh, x, cb1, gram, dout, wmix, dx, dxp, nsplit,
                            add_src, add_scale);
-    })
+    }))
     _prof.stop();
     if (nsplit > 1) {
         ProfScope _p2(TK_SMALL, s);

@@ -18,6 +18,8 @@ static inline int stats_sync(double* table, size_t ndoubles, hipStream_t s) {
 static inline uint64_t stats_world() { return (g_stats_sync.fn && g_stats_sync.world > 1) ? (uint64_t)g_stats_sync.world : 1; }
 
 // gemm_kernels.hip
+int gemm_mode();            // arithmetic of the row-tiled GEMMs (tfnas_hip.h: TFNAS_GEMM_*)
+int set_gemm_mode(int m);
 int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* stats1, float* part,
                       hipStream_t s);
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,

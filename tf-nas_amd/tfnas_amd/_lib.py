@@ -104,6 +104,8 @@ _PROTOS = {
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),
     'tfnas_prof_enable': (C.c_int, [C.c_uint]),
     'tfnas_set_lazy_join': (C.c_int, [C.c_int]),
+    'tfnas_set_gemm_mode': (C.c_int, [C.c_int]),
+    'tfnas_gemm_mode': (C.c_int, []),
     'tfnas_side_stream': (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     'tfnas_side_join': (C.c_int, [_P]),
     'tfnas_prof_count': (C.c_int, []),
