@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define TFNAS_ABI_VERSION 1
+/* 2 (round 4): arithmetic modes of the GEMMs (tfnas_set_gemm_mode); the per-group input / output mode of TfnasCellDesc (xg /
+ * og), TfnasPathDesc.dual, tfnas_path_set_side_stream2 and tfnas_path_defer_join / tfnas_path_join were measured and removed */
+#define TFNAS_ABI_VERSION 2
 #define TFNAS_MAX_GROUPS 8
 #define TFNAS_MAX_SINK 4
 #define TFNAS_MAX_CELLS 32
@@ -91,13 +93,7 @@ typedef struct TfnasCellDesc {
     int32_t stor;             /* must be 0 (fp32 storage of the [pixels][M] stream tensors E, D, dZ, dEh).  Rounds 1-3 had a
                                  second build that kept these four tensors in bf16 (stor = 1); it measured 0.99-1.04x of the
                                  fp32 iteration pair (the step is not bound by HBM bytes) and was removed.          [in] */
-    int32_t xg;               /* 1: every group has its OWN input -- x and dx are [G][N*H*W][ic] (group g at g*N*H*W*ic) and
-                                 dx[g] receives group g's gradient only; 0: one shared input, dx summed over the groups.
-                                 Requires og = 1.                                                                  [in] */
-    int32_t og;               /* 1: every group has its OWN output -- out and dout are [G][N*Ho*Wo][oc], out[g] = BN3(project_g)
-                                 (+ x[g]), wmix must be NULL; 0: the groups are mixed into one output.  og = 1 with G = 2 runs
-                                 BOTH bi-sampling paths of a weight step (train_search.py:375-379) through one launch per kernel:
-                                 twice the workgroups per launch, half the launches, one dependency chain.           [in] */
+    int32_t reserved0, reserved1;   /* must be 0 (ABI 1: xg / og, the per-group input / output mode of the removed dual paths) */
     TfnasGroup g[TFNAS_MAX_GROUPS];
 } TfnasCellDesc;
 
@@ -111,7 +107,7 @@ typedef struct TfnasCellWs {
     uint64_t off_pooled, off_gate, off_hpre;
     uint64_t stats;    /* doubles stats1[M][2] | stats2[M][2] | stats3[G*oc][2]  (sum,sumsq) */
     uint64_t off_stats1, off_stats2, off_stats3;
-    uint64_t out;      /* floats  [N*Ho*Wo][oc]   ([G][N*Ho*Wo][oc] with og = 1)                    */
+    uint64_t out;      /* floats  [N*Ho*Wo][oc]                                             */
     /* backward scratch */
     uint64_t dZ;       /* floats  [N*Ho*Wo][M]                                              */
     uint64_t dEh;      /* floats  [N*H*W][M]                                                */
@@ -119,15 +115,13 @@ typedef struct TfnasCellWs {
     uint64_t off_dgate, off_dpooled, off_dgl, off_dhpre, off_cb1;
     uint64_t red;      /* doubles red3[G*oc][2] | resdot[oc] | red2[M][2] | red1[M][2]      */
     uint64_t off_red3, off_red2, off_red1, off_resdot;   /* resdot = per-channel <dout, x> of residual cells */
-    uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd), summed in a fixed order by the
-                          producer's last workgroup or a second tiny kernel -- no floating-point atomics, deterministic
-                          results.  A multiple of tfnas_sizeof(7) floats; the LAST tfnas_sizeof(8) 4-byte words of every
-                          tfnas_sizeof(7)-float piece are ticket counters: they must be ZERO when the buffer is first
-                          passed to the library (zero them once after allocating; every call leaves them zero).
+    uint64_t part;     /* floats  scratch for per-workgroup partial sums (fwd and bwd), summed in a fixed order by a second
+                          tiny kernel -- no floating-point atomics, deterministic results.  A multiple of tfnas_sizeof(7)
+                          floats; the last tfnas_sizeof(8) 4-byte words of every tfnas_sizeof(7)-float piece are reserved.
                           Doubled when d.need_wgrad is set: tfnas_mixedop_bwd runs the weight-gradient kernels on
                           a library-owned side stream (forked from / joined to `stream` inside the call) and gives
                           them the second half.                                                              */
-    uint64_t dx;       /* floats  [N*H*W][ic]     ([G][N*H*W][ic] with xg = 1)                      */
+    uint64_t dx;       /* floats  [N*H*W][ic]                                               */
     uint64_t dxp;      /* floats  split-K partial tiles of the expand dgrad (may be tiny); pass NULL to disable */
 } TfnasCellWs;
 
@@ -151,7 +145,7 @@ int tfnas_set_stats_sync(tfnas_stats_sync_fn fn, void *user, int world);
 int tfnas_shutdown(void);
 
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 TfnasGroup, 1 TfnasCellDesc, 2 TfnasCellWs,
- * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs, 6 TfnasBnAffine;  7 = floats of one `part` scratch piece, 8 = ticket-counter
+ * 3 TfnasStage, 4 TfnasPathDesc, 5 TfnasPathWs, 6 TfnasBnAffine;  7 = floats of one `part` scratch piece, 8 = reserved
  * words at the end of each piece (TfnasCellWs.part). */
 uint64_t tfnas_sizeof(int which);
 
@@ -308,21 +302,17 @@ typedef struct TfnasPathDesc {
     int32_t soft;           /* 1: cells carry G = 8 groups, wmix/cell_lat are consumed and d wmix / d cell_lat produced */
     int32_t need_dx0;       /* backward produces the gradient of the path input                               */
     int32_t efree_mask_lo;  /* bit c set: cell c runs E-free (E never materialised; needs tfnas_efree_supported) */
-    int32_t dual;           /* 1 (sampled mode only): BOTH bi-sampling paths in this one descriptor -- every cell carries G = 2
-                               groups (group 0 = the 'gumbel' candidate, group 1 = the 'random' one) with og = 1 and, except the
-                               first cell (both paths read the same stem output), xg = 1.  Every tensor between cells is
-                               [2][N][H][W][C]; out / dout are [2][out_count/2], dx0 is ONE tensor (the sum over both paths). */
+    int32_t reserved0;      /* must be 0 (ABI 1: dual) */
     TfnasStage stage[TFNAS_MAX_STAGES];
     TfnasCellDesc cell[TFNAS_MAX_CELLS];   /* [in] fields + weight / gradient pointers bound; N, H, W chained by plan */
 } TfnasPathDesc;
 
-/* Arena requirement of a planned path, in floats (the arena must be 256-byte aligned and ZERO-FILLED once after allocation:
- * its `part` pieces hold ticket counters, see TfnasCellWs.part; the library keeps them zero afterwards). */
+/* Arena requirement of a planned path, in floats (the arena must be 256-byte aligned). */
 typedef struct TfnasPathWs {
     uint64_t saved;         /* forward results kept for backward (E, D, Pr, small tensors, statistics, cell / stage outputs) */
     uint64_t scratch;       /* forward + backward scratch (partials, dZ, dEh, gradient ring)                  */
     uint64_t total;         /* saved + scratch                                                                */
-    uint64_t out_count;     /* elements of the path output [N][Ho][Wo][oc] of the last stage (x 2 in dual mode) */
+    uint64_t out_count;     /* elements of the path output [N][Ho][Wo][oc] of the last stage */
     int32_t out_h, out_w, out_c, pad;
 } TfnasPathWs;
 
@@ -334,16 +324,6 @@ int tfnas_path_destroy(void *ctx);
  * creates.  HIP maps streams onto a few hardware queues in creation order; a caller that has measured which of its streams
  * really run concurrently (tfnas_amd/streams.py) hands the good ones in here. */
 int tfnas_path_set_side_stream(void *ctx, void *stream);
-/* Optional SECOND weight-gradient stream (caller-owned; NULL: none): the weight-gradient kernels of odd cells go there. */
-int tfnas_path_set_side_stream2(void *ctx, void *stream);
-
-/* on = 1: tfnas_paths_bwd returns WITHOUT joining this context's weight-gradient stream(s) to the path's stream; the caller
- * must call tfnas_path_join(ctx, stream) before anything reads the weight gradients or reuses the arena (the next forward of
- * the context).  Lets the work the caller enqueues after the path's backward -- the stem's backward -- overlap with the last
- * cells' weight-gradient kernels instead of waiting for them (measured: a 0.6 ms idle gap per weight step at B = 128). */
-int tfnas_path_defer_join(void *ctx, int on);
-int tfnas_path_join(void *ctx, void *stream);
-
 /* Validate + plan every cell (tfnas_cell_plan), chain the geometry (cell i+1's input extent = cell i's output), lay out
  * the arena.  May be called again on the same context with different candidates / widths (every weight step does). */
 int tfnas_path_plan(void *ctx, const TfnasPathDesc *pd, TfnasPathWs *ws);
@@ -361,7 +341,7 @@ int tfnas_paths_fwd(int npath, void *const *ctx, const float *const *x0, const f
 /* Backward of the same.  dout[p]: gradient of out[p];  dout_lat[p]: device float[nstage] or NULL;
  * produces dx0[p] (if need_dx0), dwmix[p] float[ncell][8] and dcell_lat[p] float[ncell] (soft mode), stage dbetas, and the
  * cells' weight gradients at the g_* pointers of the planned descriptors (need_wgrad cells).
- * On return every path's side stream has been joined to its stream (unless tfnas_path_defer_join is on).
+ * On return every path's side stream has been joined to its stream.
  * stage_begin / stage_end: walk only the stages [stage_begin, stage_end) (in reverse order; stage_end = -1: to the last one).
  * A backward may be issued as consecutive segments, last stages first -- (k, -1) then (0, k) -- so that the caller can start
  * reducing the late stages' weight gradients (89 % of the parameters) across ranks while the early stages are still running. */

@@ -136,13 +136,32 @@ def test_backward_without_input_grad_only_produces_dwmix():
     assert torch.allclose(w_m.grad.cpu(), w_o.grad, atol=1e-3 + 1e-3 * float(w_o.grad.abs().max()))
 
 
-def test_last_workgroup_reductions_switch():
-    """TFNAS_TAIL=1 (csrc/tail_reduce.h: statistics summed by the producer's last workgroup, off by default) must give the
-    same cell results; the switch is read once per process, hence the subprocess."""
+# Every execution variant a runtime switch can select is compared with the ORACLE (not only with the default route, which is
+# what tests/test_gpu_variants.py does): the switches are read once per process, hence one pytest child per variant running the
+# soft-mode and sampled-mode stage-by-stage comparisons above on the shapes that exercise the switched kernels.
+_DW_SHAPES = 'tiny_s2_swish_odd or wide_tile_edge or real_s1b2_56 or real_s3b1_28 or real_s4b2_14 or real_s5b2_7'
+_SE_SHAPES = 'tiny_ragged_res or real_s2b2_28 or real_s5b2_7'
+VARIANTS = {            # name: (environment, shapes, sampled-mode launches too)
+    'lds_depthwise_only': ({'TFNAS_DW': 'lds'}, _DW_SHAPES, True),
+    'register_window_depthwise_everywhere': ({'TFNAS_DW': 'direct'}, _DW_SHAPES, True),
+    'tiled_depthwise': ({'TFNAS_DW': 'tiled'}, _DW_SHAPES, True),
+    'se_fused_per_image': ({'TFNAS_SE': 'fused'}, _SE_SHAPES, True),
+    'se_lds_gemm': ({'TFNAS_SE': 'gemm'}, _SE_SHAPES, True),
+    'weight_gradients_on_the_callers_stream': ({'TFNAS_WGRAD_STREAM': '0'}, 'tiny_s1_relu_res or real_s4b2_14', True),
+    # (the permuted contraction order of the recomputed E flips one ReLU-kink element of real_s1b2_56: DESIGN.md section 4)
+    'efree_wherever_supported': ({'TFNAS_EFREE': 'all'}, 'tiny_s1_relu_res or real_s2b2_28 or real_s1b1_112', False),
+}
+
+
+@pytest.mark.parametrize('variant', sorted(VARIANTS))
+def test_variant_against_oracle(variant):
     import os, subprocess, sys
-    env = dict(os.environ, TFNAS_TAIL='1')
+    envv, shapes, sampled = VARIANTS[variant]
+    env = dict(os.environ, **envv)
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_cell.py'), '-q', '-x', '-m', 'gpu', '-k',
-                        'test_soft_mode_all_stages and (tiny or wide_tile_edge or real_s2b2_28 or real_s3b1_28)'],
-                       env=env, capture_output=True, text=True, timeout=900)
+    which = 'test_soft_mode_all_stages' + (' or (test_sampled_mode_with_weight_grads and 5-)' if sampled else '')
+    sel = '(%s) and (%s)' % (which, shapes)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_cell.py'), '-q', '-x', '-m', 'gpu', '-k', sel],
+                       env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout, r.stdout[-500:]

@@ -149,6 +149,39 @@ def test_in_place_gradients_and_lazy_join_are_bit_identical_to_the_plain_route(m
             assert torch.equal(base[k], other[k]), (direct, lazy, k)
 
 
+def test_fused_step_only_stands_in_for_an_optimizer_that_updates_every_parameter():
+    """RetrainState's fused clip + SGD updates the whole arena: with a frozen parameter or an optimizer over a subset the step
+    must take torch's tail instead (frozen / foreign parameters stay untouched, the optimizer's state_dict stays loadable), and
+    a fused step leaves what learning-rate schedulers look at (``_opt_called``) as optimizer.step() would."""
+    from tfnas_amd import model_eval as me
+    arch, mc = _arch()
+    torch.manual_seed(7)
+    m = me.Network(50, arch, mc, None, 0.0, 0.0).cuda()
+    crit = me.CrossEntropyLabelSmooth(50, 0.1)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 3, 96, 96, generator=gen).cuda()
+    y = torch.randint(0, 50, (8,), generator=gen).cuda()
+    full = torch.optim.SGD(m.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+    sched = torch.optim.lr_scheduler.StepLR(full, 1)
+    assert me.RetrainState.fusable(full, m)
+    me.train_step(m, x, y, crit, full, 5.0)
+    assert getattr(full, '_opt_called', False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                      # ("lr_scheduler.step() before optimizer.step()" would raise here)
+        sched.step()
+    frozen = m.classifier.weight
+    frozen.requires_grad_(False)
+    before = frozen.detach().clone()
+    sub = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], 0.05, momentum=0.9, weight_decay=4e-5)
+    assert not me.RetrainState.fusable(sub, m)
+    me.train_step(m, x, y, crit, sub, 5.0)
+    torch.cuda.synchronize()
+    assert torch.equal(frozen, before)                      # (weight decay / momentum of the fused kernel never touched it)
+    sub.load_state_dict(sub.state_dict())                   # (no foreign momentum entries)
+    assert frozen not in sub.state
+
+
 def test_retrain_schedule_checkpoints_and_resume(tmp_path):
     """run_retrain (train_eval.py:118-226): config + checkpoints with the reference's keys, resume continues the schedule; the
     derived network is built from a search checkpoint like `--model_path` does."""

@@ -178,10 +178,8 @@ def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
     per-cell route on one stream vs the interleaved path level on two (+ two weight-gradient streams), same torch.optim tail."""
     from tfnas_amd import search
     res = []
-    old, old_d = search.FUSED_OPT, search.DUAL_PATHS
+    old = search.FUSED_OPT
     search.FUSED_OPT = False
-    search.DUAL_PATHS = False              # (the two-stream route of round 2; the dual mode changes summation orders and is
-                                           #  compared with it in tests/test_gpu_paths.py)
     for overlap in (False, True):
         _, m = _pair(lut)
         st = search.SearchState(m)
@@ -195,7 +193,7 @@ def test_w_step_two_stream_overlap_is_bit_identical_to_single_stream(lut):
             search.w_step(st, x, y, ow, 5.0, noise_g=ng, rand_pos=rp, overlap_paths=overlap)
         torch.cuda.synchronize()
         res.append([p.detach().clone() for p in m.weight_parameters()])
-    search.FUSED_OPT, search.DUAL_PATHS = old, old_d
+    search.FUSED_OPT = old
     for a, b in zip(*res):
         assert torch.equal(a, b)
 

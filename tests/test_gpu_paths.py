@@ -21,11 +21,10 @@ def _model(lut, seed=2, T=5.0):
     return m
 
 
-def _run(lut, use_paths, pairs=2, B=8, warm=False, dual=False):
+def _run(lut, use_paths, pairs=2, B=8, warm=False):
     from tfnas_amd import search
-    old, old_f, old_d = search.USE_PATHS, search.FUSED_OPT, search.DUAL_PATHS
+    old, old_f = search.USE_PATHS, search.FUSED_OPT
     search.USE_PATHS = use_paths
-    search.DUAL_PATHS = dual               # (the dual mode changes summation orders: compared separately below)
     search.FUSED_OPT = False               # (same torch.optim tail on both sides: this test is about the path level)
     try:
         m = _model(lut)
@@ -51,7 +50,7 @@ def _run(lut, use_paths, pairs=2, B=8, warm=False, dual=False):
         torch.cuda.synchronize()
         return {k: p.detach().clone() for k, p in m.named_parameters()}, lats
     finally:
-        search.USE_PATHS, search.FUSED_OPT, search.DUAL_PATHS = old, old_f, old_d
+        search.USE_PATHS, search.FUSED_OPT = old, old_f
 
 
 @pytest.mark.parametrize('warm', [False, True])
@@ -64,64 +63,6 @@ def test_path_level_iteration_is_bit_identical_to_per_cell_route(lut, warm):
         assert abs(l1 - l2) < 1e-5                         # (the six stage latencies are summed in a different order)
         for a, b in zip(g1, g2):
             assert torch.equal(a, b)
-
-
-def _one_w_step(lut, dual, B, bi=True):
-    """Parameters after ONE weight step from the seeded initial state, and the gradients it used."""
-    from tfnas_amd import search
-    old_f, old_d = search.FUSED_OPT, search.DUAL_PATHS
-    search.DUAL_PATHS, search.FUSED_OPT = dual, False
-    try:
-        m = _model(lut)
-        st = search.SearchState(m)
-        ow, _ = search.make_optimizers(m)
-        noise = search.NoiseSource(21)
-        gen = torch.Generator(device='cuda').manual_seed(9)
-        x = torch.randn(B, 3, 224, 224, device='cuda', generator=gen)
-        y = torch.randint(0, 100, (B,), device='cuda', generator=gen)
-        loss, logits = search.w_step(st, x, y, ow, 0.0, noise.exp('cuda'), noise.rand_pos() if bi else None, bi_sampling=bi)
-        torch.cuda.synchronize()
-        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
-        return {k: p.detach().clone() for k, p in m.named_parameters()}, grads, float(loss), logits.clone()
-    finally:
-        search.FUSED_OPT, search.DUAL_PATHS = old_f, old_d
-
-
-@pytest.mark.parametrize('B', [8, 32])
-def test_dual_mode_equals_two_interleaved_paths(lut, B):
-    """TfnasPathDesc.dual (both bi-sampling paths as two groups of one descriptor: one launch per kernel for both) against
-    the two-path route of round 2.  Same kernels and arithmetic per group; what changes is the number of partial rows /
-    K-splits a launch uses (grids are sized for twice the work), i.e. fp32 summation ORDER of the batch statistics and of
-    the weight gradients: every gradient agrees to 1e-5 of its tensor's scale, the logits to 1e-5.  Tensors in or upstream of
-    the ReLU layers (stems, stage1) are judged by their relative L2 difference (<= 5e-3; observed 1.8e-3): a last-bit change of a BatchNorm
-    statistic can move a pre-activation across relu'(0), which shifts SINGLE entries of those gradients by O(1e-3..1e-2) of their
-    scale (observed 1.0e-3 on stage1.block2's expand weight at B=32) -- the two modes are each compared with the oracle under
-    replayed ReLU decisions elsewhere (tests/test_gpu_network.py, test_gpu_b128.py); this is a mode-vs-mode check."""
-    pa, ga, la, za = _one_w_step(lut, True, B)
-    pb, gb, lb, zb = _one_w_step(lut, False, B)
-    assert abs(la - lb) < 1e-5
-    assert torch.allclose(za, zb, atol=1e-5, rtol=1e-5)
-    assert set(ga) == set(gb) and len(ga) > 100
-    for k in ga:
-        ref = float(gb[k].abs().max())
-        if k.startswith(('first_stem', 'second_stem', 'stage1')):
-            rel = float((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-20))
-            assert rel <= 5e-3, (k, rel)
-        else:
-            assert float((ga[k] - gb[k]).abs().max()) <= 1e-7 + 1e-5 * ref, (k, float((ga[k] - gb[k]).abs().max()), ref)
-    for k in pa:
-        if k.startswith(('first_stem', 'second_stem', 'stage1')):
-            # (zero-initialised biases ARE lr * gradient after one step: the gradient's tolerance applies)
-            assert float((pa[k] - pb[k]).norm() / pb[k].norm().clamp_min(1e-20)) <= 5e-3, k
-        else:
-            assert torch.allclose(pa[k], pb[k], atol=1e-6, rtol=1e-5), k
-
-
-def test_dual_mode_is_bit_deterministic(lut):
-    a = _one_w_step(lut, True, 16)
-    b = _one_w_step(lut, True, 16)
-    for k in a[0]:
-        assert torch.equal(a[0][k], b[0][k]), k
 
 
 def test_weight_arena_keeps_values_and_detects_replaced_storage(lut):

@@ -140,7 +140,7 @@ extern "C" uint64_t tfnas_sizeof(int which) {
         case 5: return sizeof(TfnasPathWs);
         case 6: return sizeof(TfnasBnAffine);
         case 7: return TFNAS_PART_ALLOC;      // floats of one `part` scratch region ...
-        case 8: return TFNAS_TAIL_SLOTS;      // ... whose last this-many 4-byte words are ticket counters (zero on first use)
+        case 8: return TFNAS_TAIL_SLOTS;      // ... whose last this-many 4-byte words are reserved
         default: return 0;
     }
 }
@@ -164,12 +164,7 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
     if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
     if (d->has_res && (d->ic != d->oc || d->stride != 1)) return TFNAS_EINVAL;
-    // per-group outputs / inputs (both bi-sampling paths in one launch): MixedOP cells only; per-group inputs need per-group
-    // outputs; a residual cell with per-group outputs needs per-group inputs too (out[g] = ... + x[g])
-    if ((d->xg != 0 && d->xg != 1) || (d->og != 0 && d->og != 1)) return TFNAS_EINVAL;
-    if ((d->xg || d->og) && d->mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;
-    if (d->xg && !d->og) return TFNAS_EINVAL;
-    if (d->og && !d->xg && d->has_res) return TFNAS_EINVAL;
+    if (d->reserved0 != 0 || d->reserved1 != 0) return TFNAS_EINVAL;   // (were xg / og: per-group inputs / outputs, removed)
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
     d->Wo = (d->W - 1) / d->stride + 1;
@@ -184,21 +179,14 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         // does too): the 32-channel segments the depthwise kernels move and the 64-column GEMM tiles are then whole
         // lines.  Packed groups (72 / 144 / 120 / 336 floats wide) left most of them 32..96 bytes off, i.e. partial-line
         // writes and two lines fetched per segment.  The pad columns are never read or written.
-        static const char* noalign = getenv("TFNAS_NO_ALIGN");
-        const bool al = !(noalign && noalign[0] == '1');
-        if (al) off = (off + 31) & ~31;
+        off = (off + 31) & ~31;
         gr.off = off;
         gr.se_off = se_off;
         off += gr.mcp;
         se_off += gr.se;
     }
-    {
-        static const char* noalign = getenv("TFNAS_NO_ALIGN");
-        if (!(noalign && noalign[0] == '1')) {
-            off = (off + 31) & ~31;
-            if ((off & 511) == 0) off += 32;          // no power-of-two-ish row stride (HBM channel aliasing)
-        }
-    }
+    off = (off + 31) & ~31;
+    if ((off & 511) == 0) off += 32;                  // no power-of-two-ish row stride (HBM channel aliasing)
     d->M = off;
     d->SE = se_off;
     if ((double)d->N * d->H * d->W >= 2147483647.0) return TFNAS_ERANGE;   // row indices are int, offsets size_t
@@ -222,7 +210,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_stats2 = 2 * M;
     ws->off_stats3 = 4 * M;
     ws->stats = 4 * M + 2 * G * oc;
-    ws->out = (d->og ? G : 1) * Po * oc;
+    ws->out = Po * oc;
     ws->dZ = Po * M;
     ws->dEh = P * M;
     ws->off_dgate = 0;
@@ -237,10 +225,10 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     ws->off_red1 = ws->off_red2 + 2 * M;
     ws->red = ws->off_red1 + 2 * M;
     ws->part = (d->need_wgrad ? 2 : 1) * (uint64_t)TFNAS_PART_ALLOC;   // second half: weight-gradient side stream
-    ws->dx = (d->xg ? G : 1) * P * d->ic;
+    ws->dx = P * d->ic;
     {
         const int ns = d->mode == TFNAS_MODE_STEM ? 1 : expand_dgrad_splits(*d);
-        ws->dxp = ns > 1 ? (uint64_t)ns * (d->xg ? G : 1) * P * d->ic : 4;   /* split-K partials of the expand dgrad */
+        ws->dxp = ns > 1 ? (uint64_t)ns * P * d->ic : 4;   /* split-K partials of the expand dgrad */
     }
     return 0;
 }
@@ -325,12 +313,6 @@ static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     return 0;
 }
 
-int launch_pending_expand(PendingExpand& p, hipStream_t s) {
-    if (!p.valid) return 0;
-    p.valid = false;
-    return launch_expand_wgrad(p.d, p.dEh, p.E, p.cb1, p.x, p.part_w, s);
-}
-
 int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdBufs& b0, hipStream_t s, const CellSide* so) {
     const TfnasBnAffine* bn = b0.bn;
     TfnasCellDesc dc = d0;
@@ -375,8 +357,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     // d wmix is the only product, like autograd pruning the same sub-graph in the reference.
     if (!b.dx && !d.need_wgrad) return 0;
     // weight gradients: on the side stream, scratch = part_w
-    const bool merged = so && so->side && so->merged && so->pend;
-    if (d.need_wgrad && !merged)
+    if (d.need_wgrad)
         TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, fork_to(so, 0, s)));
     TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s)); // dZ = dP W_proj
     const bool fused2 = bn2_fused_fits(d);
@@ -392,10 +373,6 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
         // host-bound w-step; cells without SE launch nothing for it)
         hipStream_t sw = fork_to(so, 1, s);
-        if (merged) {
-            TRY(launch_pending_expand(*so->pend, sw));          // the previous cell's expand weight gradient
-            TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, sw));
-        }
         if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
         TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
     }
@@ -409,16 +386,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     } else {
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
     }
-    if (d.need_wgrad) {
-        if (merged) {
-            PendingExpand& p = *so->pend;
-            p.valid = true;
-            p.d = d;
-            p.dEh = b.dEh; p.E = b.E; p.cb1 = cb1; p.x = b.x; p.part_w = part_w;
-        } else {
-            TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
-        }
-    }
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
     if (b.dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
         float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
@@ -433,7 +401,6 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     if (!dp || !x || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
-    if (d.og && wmix) return TFNAS_EINVAL;                   // per-group outputs are not mixed
     if (!E && !efree_supported(d)) return TFNAS_ENULL;       // E may be omitted only in E-free mode (tfnas_efree_supported)
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
@@ -474,7 +441,7 @@ extern "C" int tfnas_mbconv_fwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
                                 void* stream) {
     if (!dp || !bn || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
-    if (d.mode == TFNAS_MODE_HEAD || d.G != 1 || d.xg || d.og) return TFNAS_EINVAL;
+    if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     CellFwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, part, out};

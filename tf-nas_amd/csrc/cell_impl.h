@@ -29,29 +29,13 @@ struct CellBwdBufs {
     float* dout_s = nullptr;     // scratch for drop_scale[n] * dout
 };
 
-// An expand weight gradient whose launch was put off to the NEXT cell's fork (path level, merged forks)
-struct PendingExpand {
-    bool valid = false;
-    TfnasCellDesc d;
-    const float *dEh, *E, *cb1, *x;
-    float* part_w;
-};
-
-// where the weight-gradient kernels of a cell go: `side` == nullptr -> the caller's stream.
-// merged (path level): ONE fork per cell instead of three.  Every fork is an event record on the data-gradient chain's stream
-// followed by a stream wait on the side stream, and the record costs the chain 11-16 us of idle time (rocprofv3 trace of a
-// weight step: the gaps in front of k_project_dgrad / the depthwise backward / k_expand_gram) -- 0.7 ms per chain and step
-// with three per cell.  Merged: the project / SE / depthwise weight gradients of a cell are launched at the middle fork (after
-// the BN2-backward sums), its expand weight gradient -- whose operands only exist at the end of the cell -- at the middle fork of
-// the NEXT cell (`pend`), the last one by a final fork of the caller.
+// where the weight-gradient kernels of a cell go: `side` == nullptr -> the caller's stream.  Three forks per cell (project /
+// SE + depthwise / expand weight gradients): an event record on the data-gradient chain's stream + a stream wait on the side
+// stream each.  (A one-fork-per-cell variant was measured in round 3 -- no gain -- and removed.)
 struct CellSide {
     hipStream_t side;
     hipEvent_t fork[3];
-    bool merged = false;
-    PendingExpand* pend = nullptr;
 };
-
-int launch_pending_expand(PendingExpand& p, hipStream_t s);
 
 int cell_fwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s);
 int cell_bwd_impl(const TfnasCellDesc& d, const TfnasCellWs& ws, const CellBwdBufs& b, hipStream_t s, const CellSide* so);

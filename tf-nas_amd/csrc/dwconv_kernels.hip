@@ -12,8 +12,8 @@
 // per workgroup.  Threads are (channel-quad, strip) pairs; a strip is 4 consecutive pixels along W, so every
 // LDS access is one ds_read_b128 of 4 channels and the k-wide sliding window lives in registers.  Tile loads
 // are issued 4 at a time per thread before any of them is consumed (memory-level parallelism).
+#include <cstring>
 #include "tfnas_dev.h"
-#include "tail_reduce.h"
 #include "kernels.h"
 #include "prof.h"
 #include "efree.h"
@@ -56,7 +56,7 @@ __device__ __forceinline__ bool dw_locate(const TfnasCellDesc& d, int cy, int CC
 // per-channel totals as this workgroup's partial pair: acc[2*c + which] (acc = row blockIdx.x of the partials
 // matrix, already offset to the group's first channel); k_reduce_rows sums the rows afterwards
 __device__ __forceinline__ void dw_flush_pair(f32x4 a, f32x4 b, float* red, int CC, int c0, int mcp, float* acc,
-                                              bool coherent = false) {
+                                              bool = false) {
     const int tid = threadIdx.x, CQ = CC >> 2;
     __syncthreads();
     st4(red + tid * 8, a);
@@ -69,43 +69,17 @@ __device__ __forceinline__ void dw_flush_pair(f32x4 a, f32x4 b, float* red, int 
             s += red[t * 8 + comp];
             q += red[t * 8 + 4 + comp];
         }
-        if (coherent) {          // read back by the last workgroup of this chunk (tail_reduce.h)
-            st_coherent(acc + 2 * (size_t)(c0 + tid) + 0, s);
-            st_coherent(acc + 2 * (size_t)(c0 + tid) + 1, q);
-        } else {
-            acc[2 * (size_t)(c0 + tid) + 0] = s;
-            acc[2 * (size_t)(c0 + tid) + 1] = q;
-        }
+        acc[2 * (size_t)(c0 + tid) + 0] = s;
+        acc[2 * (size_t)(c0 + tid) + 1] = q;
     }
 }
 
-// Statistics epilogue of the depthwise kernels: this workgroup's partial pair row (row `lane` of `nrows`), then -- if the
-// launch has ticket counters -- the last workgroup of the channel chunk sums the rows into tail.out ((sum, sumsq) pairs of
-// BN2, or (T1, T2) of the BN1 backward together with the cb1 table = (mean1, rstd1, T1/P, T2/P), zeros for pad channels).
-__device__ __forceinline__ void dw_flush_tail(f32x4 a, f32x4 b, float* lds, int CC, int c0, int mc, int mcp, int off, int M,
-                                              float* part, int lane, int nrows, int chunk, const DwTail& tail,
-                                              const double* stats1, double inv1, float eps) {
-    dw_flush_pair(a, b, lds, CC, c0, mcp, part + (size_t)lane * 2 * M + 2 * (size_t)off, tail.cnt != nullptr);
-    if (!tail.cnt) return;
-    if (!tail_ticket(tail.cnt + chunk, nrows, lds)) return;
-    const int nch = min(CC, mcp - c0);
-    tail_reduce_cols(part, TFNAS_PART_FLOATS, 2 * (size_t)M, nrows, 2 * (off + c0), 2 * nch, lds,
-                     [&](int c, double t0, double t1) {
-                         tail.out[c] = t0;
-                         tail.out[c + 1] = t1;
-                         if (tail.cb1) {
-                             const int ch = c >> 1;
-                             f32x4 t = zero4();
-                             if (ch - off < mc) {
-                                 const float2 m = bn_consts(stats1 + 2 * (size_t)ch, inv1, eps);
-                                 t.x = m.x;
-                                 t.y = m.y;
-                                 t.z = (float)(t0 * inv1);
-                                 t.w = (float)(t1 * inv1);
-                             }
-                             reinterpret_cast<f32x4*>(tail.cb1)[ch] = t;
-                         }
-                     });
+// Statistics epilogue of the depthwise kernels: this workgroup's partial pair row (row `lane`); a k_reduce_rows / k_reduce_bn1
+// launch sums the rows in double.  (Rounds 2-3 also had the producer's last workgroup sum them -- ticket counters + coherent
+// read-back; measured no faster in two rounds and removed)
+__device__ __forceinline__ void dw_flush_stats(f32x4 a, f32x4 b, float* lds, int CC, int c0, int mcp, int off, int M, float* part,
+                                               int lane) {
+    dw_flush_pair(a, b, lds, CC, c0, mcp, part + (size_t)lane * 2 * M + 2 * (size_t)off);
 }
 
 __device__ __forceinline__ void stage_weights(float* wts, const float* __restrict__ w, int KK, int CC, int c0, int mc) {
@@ -183,7 +157,7 @@ template <int K, int S, int ACT, int KQ>
 __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float* __restrict__ E,
                                                    const float* __restrict__ x,
                                                    const double* __restrict__ stats1, float* __restrict__ D,
-                                                   float* __restrict__ part, DwGeom gm, DwTail tail) {
+                                                   float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int g, c0, lane = blockIdx.x, cy = blockIdx.y;
     if (KQ > 0) efree_lane_chunk(lane, cy);
@@ -273,7 +247,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_fwd(TfnasCellDesc d, const float*
             }
         }
     }
-    dw_flush_tail(ssum, ssq, in_tile, CC, c0, mc, mcp, off, M, part, lane, gridDim.x, cy, tail, nullptr, 0.0, 0.f);
+    dw_flush_stats(ssum, ssq, in_tile, CC, c0, mcp, off, M, part, lane);
 }
 
 // ---------------------------------------------------------------------------- BN2-backward operand
@@ -326,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
                                                         const double* __restrict__ red2, const float* __restrict__ E,
                                                         const float* __restrict__ x,
                                                         const double* __restrict__ stats1, float* __restrict__ dEh,
-                                                        float* __restrict__ part, DwGeom gm, DwTail tail) {
+                                                        float* __restrict__ part, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int g, c0, lane = blockIdx.x, cy = blockIdx.y;
     if (KQ > 0) efree_lane_chunk(lane, cy);
@@ -468,8 +442,7 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
             }
         }
     }
-    dw_flush_tail(t1, t2, dd_tile, CC, c0, mc, mcp, off, M, part, lane, gridDim.x, cy, tail, stats1,
-                  1.0 / ((double)d.N * H * W), d.eps);
+    dw_flush_stats(t1, t2, dd_tile, CC, c0, mcp, off, M, part, lane);
 }
 
 // ============================================================================ weight gradient
@@ -699,7 +672,6 @@ static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const flo
     if (ef && !efree_ic_ok(d.ic)) return TFNAS_EINVAL;
     const int kq = ef ? d.ic / 4 : 0;
     const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 4096, 2 * (size_t)d.M, ef);
-    const DwTail tail = {tail_enabled() ? tail_counters(part) : nullptr, stats2, nullptr};
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
         pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm, ef);
@@ -711,10 +683,9 @@ static int launch_dw_fwd_tiled(const TfnasCellDesc& d, const float* E, const flo
         ProfScope _prof(TK_DW_FWD, s, d.G > 2);
         if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
         DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
-            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, E, x, stats1, D, part, gm, tail);
+            hipLaunchKernelGGL((k_dw_fwd<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, E, x, stats1, D, part, gm);
         }))
     }
-    if (tail.cnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
@@ -726,7 +697,6 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
     if (ef && !efree_ic_ok(d.ic)) return TFNAS_EINVAL;
     const int kq = ef ? d.ic / 4 : 0;
     const int gx = dw_common_gx(d, d.H, d.W, false, 4096, 2 * (size_t)d.M, ef);
-    const DwTail tail = {tail_enabled() ? tail_counters(part) : nullptr, red1, cb1};
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
         pick_tile(d.N, d.H, d.W, kk, d.stride, false, gm, ef);
@@ -740,10 +710,9 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
         ProfScope _prof(TK_DW_BWD_DATA, s, d.G > 2);
         DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
             hipLaunchKernelGGL((k_dw_bwd_data<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2,
-                               red2, E, x, stats1, dEh, part, gm, tail);
+                               red2, E, x, stats1, dEh, part, gm);
         }))
     }
-    if (tail.cnt) return (int)hipGetLastError();
     if (cb1) return launch_reduce_bn1(d, part, gx, stats1, red1, cb1, s);
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
@@ -782,6 +751,16 @@ static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const 
 static int launch_dw_wgrad_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                   const float* D, const double* stats2, const double* red2, const float* E,
                                   const double* stats1, float* part, size_t out_size, hipStream_t s, bool& done);
+// TFNAS_DW = auto (default: per launch, whichever kernel measured faster) | direct (register-window kernels wherever the geometry
+// allows) | lds (ring / tile kernels only) | tiled (tile kernels only): every choice is compared with the oracle
+// (tests/test_gpu_cell.py::test_variant_against_oracle)
+static int dw_variant() {
+    static const int v = [] {
+        const char* e = getenv("TFNAS_DW");
+        return !e ? 0 : !strcmp(e, "direct") ? 1 : !strcmp(e, "lds") ? 2 : !strcmp(e, "tiled") ? 3 : 0;
+    }();
+    return v;
+}
 static bool dwd_enabled();
 static int launch_dw_bwd_data_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                      const float* D, const double* stats2, const double* red2, const float* E,

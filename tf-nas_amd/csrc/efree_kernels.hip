@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_stats1_gram(TfnasCellDesc d, const doub
 }
 
 bool efree_supported(const TfnasCellDesc& d) {
-    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad || d.xg || d.og || !efree_ic_ok(d.ic)) return false;
+    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad || !efree_ic_ok(d.ic)) return false;
     if (stats_sync_on()) return false;          // (cross-rank statistics are reduced on the (sum, sumsq) tables of E)
     if ((size_t)d.N * d.H * d.W * d.ic >= ((size_t)1 << 31)) return false;
     for (int g = 0; g < d.G; ++g)

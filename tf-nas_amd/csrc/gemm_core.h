@@ -18,7 +18,6 @@
 // wrow = 32 * wave.
 #pragma once
 #include "tfnas_dev.h"
-#include "tail_reduce.h"
 
 template <int NT>
 struct GT {
@@ -313,7 +312,7 @@ __device__ __forceinline__ void acc_colstats(const f32x4 (&acc)[2][NT], float (&
 //  partials + reduce is also bit-reproducible.)
 template <int NT>
 __device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], float* lds, float* part_row,
-                                               int col0, int col_lim, bool coherent = false) {
+                                               int col0, int col_lim) {
     using T = GT<NT>;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15;
 #pragma unroll
@@ -338,13 +337,8 @@ __device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], f
             ss += lds[(ww * 2 + 0) * T::BN + tid];
             qq += lds[(ww * 2 + 1) * T::BN + tid];
         }
-        if (coherent) {      // read back by another workgroup of this launch (tail_reduce_cols)
-            st_coherent(part_row + 2 * (size_t)(col0 + tid) + 0, ss);
-            st_coherent(part_row + 2 * (size_t)(col0 + tid) + 1, qq);
-        } else {
-            part_row[2 * (size_t)(col0 + tid) + 0] = ss;
-            part_row[2 * (size_t)(col0 + tid) + 1] = qq;
-        }
+        part_row[2 * (size_t)(col0 + tid) + 0] = ss;
+        part_row[2 * (size_t)(col0 + tid) + 1] = qq;
     }
     __syncthreads();
 }

@@ -78,8 +78,7 @@ struct RawWS { f32x4 w; float s; };      // a weight quad and its row scale
 // epilogue: per-workgroup partial (sum, sumsq) of E per channel -> part (reduced into stats1 = BN1 statistics)
 template <int NT, bool STEM, int MM>
 __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_fwd(TfnasCellDesc d, const float* __restrict__ x,
-                                                    float* __restrict__ E, float* __restrict__ part,
-                                                    unsigned* __restrict__ tail_cnt, double* __restrict__ stats1) {
+                                                    float* __restrict__ E, float* __restrict__ part) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     int ty = blockIdx.y, g = 0;
@@ -94,7 +93,6 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_fwd(TfnasCellDe
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7, nchunks = (ic + 15) >> 4;
     const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
-    if (!STEM && d.xg) x += (size_t)g * P * ic;            // every group has its own input (the two bi-sampling paths)
 
     float cs[NT], cq[NT];
 #pragma unroll
@@ -137,13 +135,7 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_fwd(TfnasCellDe
         });
         acc_colstats<NT>(acc, cs, cq);
     }
-    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp, tail_cnt != nullptr);
-    if (tail_cnt && tail_ticket(tail_cnt + blockIdx.y, gridDim.x, lds)) {
-        // BN1 statistics of this column tile, summed by the workgroup that finished last
-        const int nc = 2 * (min(mcp, n0 + T::BN) - n0);
-        tail_reduce_cols(part, TFNAS_PART_FLOATS, 2 * (size_t)M, gridDim.x, 2 * (off + n0), nc, lds,
-                         [&](int c, double t0, double t1) { stats1[c] = t0; stats1[c + 1] = t1; });
-    }
+    flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * M + 2 * (size_t)off, n0, mcp);
 }
 
 // ============================================================================ project forward
@@ -155,8 +147,7 @@ template <int NT, int ACT, int MM>
 __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_fwd(TfnasCellDesc d, const float* __restrict__ D,
                                                      const float* __restrict__ gate,
                                                      const double* __restrict__ stats2, float* __restrict__ Pr,
-                                                     float* __restrict__ part, int nsplit, float* __restrict__ prp,
-                                                     unsigned* __restrict__ tail_cnt, double* __restrict__ stats3) {
+                                                     float* __restrict__ part, int nsplit, float* __restrict__ prp) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // nsplit > 1 (under-filled launches: few row tiles, long K): K-split ks of group g adds chunks [cb, ce); split 0
@@ -243,16 +234,8 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_fwd(TfnasCellD
         });
         acc_colstats<NT>(acc, cs, cq);
     }
-    if (nsplit == 1) {
-        flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc,
-                           tail_cnt != nullptr);
-        if (tail_cnt && tail_ticket(tail_cnt + blockIdx.y + gridDim.y * blockIdx.z, gridDim.x, lds)) {
-            // BN3 statistics of this (group, column tile), summed by the workgroup that finished last
-            const int nc = 2 * (min(oc, n0 + T::BN) - n0);
-            tail_reduce_cols(part, TFNAS_PART_FLOATS, 2 * (size_t)d.G * oc, gridDim.x, 2 * (g * oc + n0), nc, lds,
-                             [&](int c, double t0, double t1) { stats3[c] = t0; stats3[c + 1] = t1; });
-        }
-    }
+    if (nsplit == 1)
+        flush_colstats<NT>(cs, cq, lds, part + (size_t)blockIdx.x * 2 * d.G * oc + 2 * (size_t)g * oc, n0, oc);
 }
 
 // Pr[g][p][:] += sum_z prp[z][g][p][:] and the per-workgroup partial (sum, sumsq) of the finished Pr per (g, column):
@@ -388,7 +371,6 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_dgrad(TfnasCel
     f32x4* tab = reinterpret_cast<f32x4*>(lds + T::LDS_FLOATS);
     bn3_fold_fill(tab, ocp, d, g, stats3, red3, wmix);
     __syncthreads();
-    if (d.og) dout += (size_t)g * Po * oc;                 // every group has its own output gradient
 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
         f32x4 acc[2][NT];
@@ -463,7 +445,6 @@ __global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const fl
     const int r0 = blockIdx.x * rows_per_split, r1 = min(Po, r0 + rows_per_split);
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
-    if (d.og) dout += (size_t)g * Po * oc;
 
     const Bn3Tab tab = bn3_tab_fill(lds + T::LDS_FLOATS, ocp, d, g, stats3, red3, wmix);
     // A thread stages the same 4 mid channels (A) and the same 4 output channels per B item in every K-chunk; only the
@@ -614,24 +595,13 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
     const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
     const int nrt = (P + 127) >> 7;
     const int tid = threadIdx.x, lr = tid & 15, wrow = (tid >> 6) * 32;
-    // xg = 1 (every group has its own input, the two bi-sampling paths): blockIdx.z = group * nsplit + split; the K range is
-    // that group's mid channels (+ its own x / -G chunks), all operand / result pointers move to the group's slice
-    const int gsel = d.xg ? (int)blockIdx.z / nsplit : -1;
-    const int zs = d.xg ? (int)blockIdx.z - gsel * nsplit : (int)blockIdx.z;
+    const int zs = (int)blockIdx.z;
     int mchunks = 0;
-    if (gsel >= 0) mchunks = (d.g[gsel].mcp + 15) >> 4;
-    else for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
     const int nchunks_all = mchunks + ((ic + 15) >> 4);      // mid-channel chunks, then the x / -G chunks
     const int per = (nchunks_all + nsplit - 1) / nsplit;
     const int cbeg = zs * per;
     const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
-    if (gsel > 0) {
-        x += (size_t)gsel * P * ic;
-        dx += (size_t)gsel * P * ic;
-        gram += (size_t)gsel * (size_t)(ic + 4) * ic;
-        if (dout) dout += (size_t)gsel * P * d.oc;           // (only read by residual cells: ic == oc, P == Po)
-        if (add_src) add_src += (size_t)gsel * P * ic;
-    }
     float* __restrict__ dst = nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx;
     const bool add_res = d.has_res && nsplit == 1;
     const bool add_sink = add_src != nullptr && nsplit == 1;
@@ -664,13 +634,11 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
                 return;
             }
             int g = 0;
-            if (gsel >= 0) g = gsel;
-            else
-                for (; g < d.G - 1; ++g) {
-                    const int t = (d.g[g].mcp + 15) >> 4;
-                    if (c < t) break;
-                    c -= t;
-                }
+            for (; g < d.G - 1; ++g) {
+                const int t = (d.g[g].mcp + 15) >> 4;
+                if (c < t) break;
+                c -= t;
+            }
             is_x = false;
             k0 = c * 16;
             klim_a = d.g[g].mcp;
@@ -724,14 +692,6 @@ __global__ __launch_bounds__(256) void k_dx_reduce(TfnasCellDesc d, const float*
     const float sink_w = add_src ? add_scale[0] : 0.f;
     const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
     const int iq = d.ic / 4;
-    if (d.xg) {                                              // blockIdx.y = group: its own partial tiles, operator, gradient slice
-        const size_t g = blockIdx.y;
-        dxp += g * (size_t)nsplit * n4 * 4;
-        gram += g * (size_t)(d.ic + 4) * d.ic;
-        dx += g * n4 * 4;
-        if (dout) dout += g * n4 * 4;
-        if (add_src) add_src += g * n4 * 4;
-    }
     const float* __restrict__ bias = gram + (size_t)d.ic * d.ic;
     float sumw = 1.f;
     if (wmix) {
@@ -758,13 +718,9 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     const int ic = d.ic;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.z * T::BN;
-    // xg = 1: one operator PER GROUP (every group back-propagates into its own input): blockIdx.x = group * nsplit + split,
-    // partial tile of (group, split) at part[blockIdx.x]
-    const int gsel = d.xg ? (int)blockIdx.x / nsplit : -1;
-    const int xs = d.xg ? (int)blockIdx.x - gsel * nsplit : (int)blockIdx.x;
+    const int xs = (int)blockIdx.x;             // K-split: partial tile at part[blockIdx.x]
     int mchunks = 0;
-    if (gsel >= 0) mchunks = (d.g[gsel].mcp + 15) >> 4;
-    else for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
+    for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
     const int cbeg = xs * chunks_per_split;
     const int nchunks = max(0, min(mchunks, cbeg + chunks_per_split) - cbeg);
     const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
@@ -776,13 +732,11 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
     auto locate = [&](int c, int& g, int& k0) {
         c += cbeg;
         g = 0;
-        if (gsel >= 0) g = gsel;
-        else
-            for (; g < d.G - 1; ++g) {
-                const int t = (d.g[g].mcp + 15) >> 4;
-                if (c < t) break;
-                c -= t;
-            }
+        for (; g < d.G - 1; ++g) {
+            const int t = (d.g[g].mcp + 15) >> 4;
+            if (c < t) break;
+            c -= t;
+        }
         k0 = c * 16;
     };
     auto fa = [&](int c, int kl, int m) -> f32x4 {       // A(m..m+3, k) = s_k W[k][m..m+3]; row ic = coef_k
@@ -845,7 +799,6 @@ __global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const flo
     const int r0 = blockIdx.x * rows_per_split, r1 = min(P, r0 + rows_per_split);
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
-    if (!STEM && d.xg) x += (size_t)g * P * ic;
 
     // per-thread constants of the K loop (see k_project_wgrad): the thread's 4 mid channels and its BN1-backward constants,
     // folded:  de = rstd (deh - t1 - (E - mu) rstd t2)  =  rstd deh - rstd t1 - (E - mu) (rstd^2 t2)
@@ -964,9 +917,7 @@ int set_gemm_mode(int m) {
 // kernels with a statistics epilogue: at most 1024 partial rows (k_reduce_rows folds 512 per round trip) and they must fit
 static size_t stats_row_cap(size_t row_floats) {
     const size_t fit = TFNAS_PART_FLOATS / (row_floats ? row_floats : 1);
-    // "last workgroup reduces" (tail_reduce_cols): one workgroup sums a column tile over all rows -- keep that tail short
-    static const size_t lim = getenv("TFNAS_TAIL_ROWS") ? (size_t)atoi(getenv("TFNAS_TAIL_ROWS")) : 1024;
-    return fit < lim ? fit : lim;
+    return fit < 1024 ? fit : 1024;
 }
 
 // Number of persistent row blocks (grid.x) of a row-tiled GEMM launch.  The launch runs gx * other workgroups on
@@ -982,13 +933,6 @@ static int row_blocks(int rows, int other_blocks, size_t cap = 1u << 30, int slo
     if ((size_t)lim > cap) lim = (int)cap;
     if (lim > max_gx) lim = max_gx;                    // (bounds the host-side search; measured per kernel family)
     if (lim < 1) lim = 1;
-    static const char* legacy = getenv("TFNAS_ROWBLOCKS_LEGACY");
-    if (legacy && legacy[0] == '1') {
-        int want = cdiv(4096, other);
-        if ((size_t)want > cap) want = (int)cap;
-        if (want < 1) want = 1;
-        return nrt < want ? nrt : want;
-    }
     long best_cost = -1;
     int best = 1;
     for (int gx = 1; gx <= lim; ++gx) {
@@ -1012,27 +956,21 @@ static inline int gemm_mode_for(const TfnasCellDesc& d) {
 // The data-gradient GEMMs gain little from the bf16 pipe (their K loops are bound by the BN3-backward transform / the chunk ->
 // group bookkeeping and, with one candidate or large images, by bytes): measured per cell at B = 128 (tools/r4_cf.sh), split-bf16
 // vs fp32 MFMA: all-candidate launches of the 14x14 / 7x7 cells 0.94-0.98x, 28x28 up to 1.19x, one-candidate launches 0.9-1.8x.
-// They keep the fp32 loop except where they won; TFNAS_GEMM_DGRAD=1 / 0 forces the choice.
+// They keep the fp32 loop except where they won.
 static inline int gemm_mode_dgrad(const TfnasCellDesc& d) {
-    static const int force = getenv("TFNAS_GEMM_DGRAD") ? atoi(getenv("TFNAS_GEMM_DGRAD")) : -1;
     const int m = gemm_mode_for(d);
-    if (m == 0 || force == 1 || g_gemm_everywhere) return m;
-    if (force == 0) return 0;
+    if (m == 0 || g_gemm_everywhere) return m;
     if (m == 1) return m;                                  // plain bf16 is a reduced-precision MODE, not a policy: everywhere
     return (d.G > 1 && d.Ho * d.Wo <= 196) ? m : 0;
 }
-static inline int gemm_mode_fwd(const TfnasCellDesc& d, int hw) {
-    static const int maxhw = getenv("TFNAS_X3_MAXHW_FWD") ? atoi(getenv("TFNAS_X3_MAXHW_FWD")) : (1 << 30);
-    const int m = gemm_mode_for(d);
-    return (m == 1 || hw <= maxhw || g_gemm_everywhere) ? m : 0;
+static inline int gemm_mode_fwd(const TfnasCellDesc& d, int /*hw*/) {
+    return gemm_mode_for(d);
 }
 
 // Column-tile width of the GEMMs whose N extent is the mid channels of EVERY group (tiles cannot straddle groups): the
 // candidate that pads the group widths least (72 | 144 -> 5 x 16: 960 columns for 864, where 4 x 16 needs 1280 and
-// 20 tiles instead of 12; 336 | 672 -> 7 x 16 exactly), the wider one on ties.  TFNAS_NT_GROUPS=0: always 4.
+// 20 tiles instead of 12; 336 | 672 -> 7 x 16 exactly), the wider one on ties.
 static int pick_nt_groups(const TfnasCellDesc& d) {
-    static const char* e = getenv("TFNAS_NT_GROUPS");
-    if (e && e[0] == '0') return 4;
     // only for cells with narrow groups (the HBM-bound 56x56 / 28x28 cells): on the matrix-bound later cells the 64-wide
     // tile at 4 waves/SIMD beats the 80- / 112-wide ones at 3 even when those fit exactly (measured)
     int min_mcp = 1 << 30;
@@ -1061,21 +999,19 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
     const int mm = gemm_mode_fwd(d, d.H * d.W);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles, stats_row_cap(2 * (size_t)d.M), gemm_slots(nt, mm)), tiles);
-    unsigned* tcnt = (tail_enabled() && tiles <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
     DISPATCH_MM_(mm, {
         if (d.mode == TFNAS_MODE_STEM) {
-            if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
-            else hipLaunchKernelGGL((k_expand_fwd<4, true, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1);
+            if (nt == 2) hipLaunchKernelGGL((k_expand_fwd<2, true, MM>), grid, dim3(256), 0, s, d, x, E, part);
+            else hipLaunchKernelGGL((k_expand_fwd<4, true, MM>), grid, dim3(256), 0, s, d, x, E, part);
         } else {
             switch (nt) {
-                case 5: hipLaunchKernelGGL((k_expand_fwd<5, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
-                case 7: hipLaunchKernelGGL((k_expand_fwd<7, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
-                default: hipLaunchKernelGGL((k_expand_fwd<4, false, MM>), grid, dim3(256), 0, s, d, x, E, part, tcnt, stats1); break;
+                case 5: hipLaunchKernelGGL((k_expand_fwd<5, false, MM>), grid, dim3(256), 0, s, d, x, E, part); break;
+                case 7: hipLaunchKernelGGL((k_expand_fwd<7, false, MM>), grid, dim3(256), 0, s, d, x, E, part); break;
+                default: hipLaunchKernelGGL((k_expand_fwd<4, false, MM>), grid, dim3(256), 0, s, d, x, E, part); break;
             }
         }
     })
     _prof.stop();
-    if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
@@ -1092,8 +1028,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
     // K-chunks back to back at ~2 us per chunk -- one workgroup per CU cannot hide the load latency)
     int nsplit = 1;
     const int wgs = nrt * tiles * d.G, kch = cdiv(mcp_max, 16);
-    static const char* nosplit = getenv("TFNAS_PROJECT_NOSPLIT");
-    if (wgs < 512 && kch >= 16 && (d.oc & 3) == 0 && d.oc <= 1024 && !(nosplit && nosplit[0] == '1')) {
+    if (wgs < 512 && kch >= 16 && (d.oc & 3) == 0 && d.oc <= 1024) {
         nsplit = cdiv(1024, wgs);
         if (nsplit > 4) nsplit = 4;
         if (nsplit > kch / 8) nsplit = kch / 8;
@@ -1106,8 +1041,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         dim3 grid(nrt, tiles, d.G * nsplit);
         DISPATCH_MM_(mm, DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
             const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
-            hipLaunchKernelGGL((k_project_fwd<NT, ACT, MM>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp,
-                               (unsigned*)nullptr, (double*)nullptr);
+            hipLaunchKernelGGL((k_project_fwd<NT, ACT, MM>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, nsplit, prp);
         })))
         int gx2 = cdiv(Po, 64);
         if (gx2 > 256) gx2 = 256;
@@ -1118,14 +1052,12 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         return launch_reduce_rows(part2, gx2, ncols2, (size_t)ncols2, stats3, nullptr, s);
     }
     dim3 grid(row_blocks(Po, tiles * d.G, stats_row_cap((size_t)ncols2), gemm_slots(nt, mm)), tiles, d.G);
-    unsigned* tcnt = (tail_enabled() && tiles * d.G <= (int)TFNAS_TAIL_SLOTS) ? tail_counters(part) : nullptr;
     DISPATCH_MM_(mm, DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 2 * ((mcp_max + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_fwd<NT, ACT, MM>), grid, dim3(256), shm, s, d, D, gate, stats2, Pr, part, 1,
-                           (float*)nullptr, tcnt, stats3);
+                           (float*)nullptr);
     })))
     _prof.stop();
-    if (tcnt) return (int)hipGetLastError();
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
 }
 
@@ -1145,8 +1077,8 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
 
 static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
     // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split, partial tiles must fit the scratch
-    static const int target = getenv("TFNAS_WGRAD_WGS") ? atoi(getenv("TFNAS_WGRAD_WGS")) : 1024;
-    static const int min_rows = getenv("TFNAS_WGRAD_MINROWS") ? atoi(getenv("TFNAS_WGRAD_MINROWS")) : 256;
+    // (swept 512 ... 2048 workgroups x 128 ... 512 rows: flat within 2 %, worse below)
+    const int target = 1024, min_rows = 256;
     int splits = cdiv(target, out_tiles > 0 ? out_tiles : 1);
     const size_t cap = TFNAS_PART_FLOATS / (out_size > 0 ? out_size : 1);
     if ((size_t)splits > cap) splits = (int)cap;
@@ -1156,25 +1088,9 @@ static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
     return ((rps + 15) / 16) * 16;
 }
 
-// Under-filled launches (fewer workgroups than resident slots): ask for enough dynamic LDS that a CU cannot take more than
-// its even share ceil(wgs / 256) -- experiment knob TFNAS_SPREAD=1 (does the dispatcher pack CUs?)
-static size_t spread_lds(size_t shm, long wgs) {
-    static const char* e = getenv("TFNAS_SPREAD");
-    if (!e || e[0] != '1') return shm;
-    const long per_cu = (wgs + 255) / 256;
-    size_t want = (size_t)(160 * 1024) / (size_t)(per_cu > 0 ? per_cu : 1);
-    if (want > 64 * 1024) want = 64 * 1024;
-    want &= ~(size_t)255;
-    return want > shm ? want : shm;
-}
-
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s) {
-    {
-        int rc = 0;
-        if (launch_project_wgrad_tn(d, dout, Pr, D, gate, stats2, stats3, red3, wmix, part, s, &rc)) return rc;
-    }
     ProfScope _prof(TK_PROJECT_WGRAD, s);
     const int nt = pick_nt(d.oc, kNtSmall, 6);
     const int Po = d.N * d.Ho * d.Wo;
@@ -1187,7 +1103,6 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
     dim3 grid(cdiv(Po, rps), mtiles, ntiles * d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
-        shm = spread_lds(shm, (long)grid.x * grid.y * grid.z);
         hipLaunchKernelGGL((k_project_wgrad<NT, ACT>), grid, dim3(256), shm, s, d, dout, Pr, D, gate, stats2,
                            stats3, red3, wmix, rps, ntiles, part, out_size);
     }))
@@ -1205,14 +1120,10 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
 // K-splits of expand dgrad: only when the (row tile x column tile) grid cannot fill the chip
 int expand_dgrad_splits(const TfnasCellDesc& d) {
     const int nt = pick_nt(d.ic, kNtSmall, 6);
-    const int tiles = cdiv(d.N * d.H * d.W, 128) * cdiv(d.ic, 16 * nt) * (d.xg ? d.G : 1);
+    const int tiles = cdiv(d.N * d.H * d.W, 128) * cdiv(d.ic, 16 * nt);
     if (tiles >= 512) return 1;
     int nchunks = 0;
-    if (d.xg) {                                       // per-group K ranges: the narrowest group bounds the split count
-        nchunks = 1 << 30;
-        for (int g = 0; g < d.G; ++g) nchunks = cdiv(d.g[g].mcp, 16) < nchunks ? cdiv(d.g[g].mcp, 16) : nchunks;
-    } else
-        for (int g = 0; g < d.G; ++g) nchunks += cdiv(d.g[g].mcp, 16);
+    for (int g = 0; g < d.G; ++g) nchunks += cdiv(d.g[g].mcp, 16);
     int ns = cdiv(1024, tiles);
     if (ns > 16) ns = 16;
     if (ns > nchunks / 4) ns = nchunks / 4;      // at least 4 K-chunks per split
@@ -1220,20 +1131,17 @@ int expand_dgrad_splits(const TfnasCellDesc& d) {
 }
 
 // floats of the correction operator G | b
-size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.xg ? d.G : 1) * (size_t)(d.ic + 4) * d.ic; }
+size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.ic + 4) * d.ic; }
 
 // G | b -> gram ([ic+4][ic] floats); `scratch` holds the K-split partials (scratch_floats available)
 int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
                        hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
-    const int ng = d.xg ? d.G : 1;                                // operators to build (one per group with per-group inputs)
+    const int ng = 1;
     const size_t gsz = (size_t)(d.ic + 4) * d.ic;
-    int mchunks = 0;                                              // K-chunks of one operator (xg: of the widest group)
-    for (int g = 0; g < d.G; ++g) {
-        const int c = cdiv(d.g[g].mcp, 16);
-        mchunks = d.xg ? (c > mchunks ? c : mchunks) : mchunks + c;
-    }
+    int mchunks = 0;                                              // K-chunks of the operator
+    for (int g = 0; g < d.G; ++g) mchunks += cdiv(d.g[g].mcp, 16);
     const int mtiles = cdiv(d.ic + 1, 128), ntiles = cdiv(d.ic, 16 * nt);
     int splits = cdiv(512, mtiles * ntiles * ng);
     if (splits > mchunks / 4) splits = mchunks / 4;               // at least 4 K-chunks per split
@@ -1255,7 +1163,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int tiles = cdiv(d.ic, 16 * nt);
     const int nsplit = dxp ? expand_dgrad_splits(d) : 1;
-    const int ng = d.xg ? d.G : 1;
+    const int ng = 1;
     const int mm = gemm_mode_dgrad(d);
     dim3 grid(row_blocks(d.N * d.H * d.W, tiles * nsplit * ng, 1u << 30, gemm_slots(nt, mm), 4096), tiles, nsplit * ng);
     DISPATCH_MM_(mm, DISPATCH_NT(nt, {
@@ -1276,10 +1184,6 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
 
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s) {
-    {
-        int rc = 0;
-        if (launch_expand_wgrad_tn(d, dEh, E, cb1, x, part, s, &rc)) return rc;
-    }
     ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;

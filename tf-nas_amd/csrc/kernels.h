@@ -39,13 +39,6 @@ int expand_dgrad_splits(const TfnasCellDesc& d);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s);
 
-// wgrad_tn.hip: wave-level TN GEMMs (no LDS staging) for the two 1x1 weight gradients; return false when not applicable
-bool launch_project_wgrad_tn(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D, const float* gate,
-                             const double* stats2, const double* stats3, const double* red3, const float* wmix, float* part,
-                             hipStream_t s, int* rc);
-bool launch_expand_wgrad_tn(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1, const float* x,
-                            float* part, hipStream_t s, int* rc);
-
 // dwconv_kernels.hip
 // E == nullptr: E-free mode (efree.h) -- the expanded activation is recomputed from x inside the depthwise kernels
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const float* x, const double* stats1, float* D,
@@ -94,28 +87,11 @@ int launch_head_bwd(const TfnasCellDesc& d, const float* E, const double* stats1
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s, int nbatch = 1, size_t in_stride = 0, size_t out_stride = 0);
 /* One `part` scratch region = TFNAS_PART_ALLOC floats (16 MiB): TFNAS_PART_FLOATS for per-workgroup partial rows / split-K
-   tiles, then TFNAS_TAIL_SLOTS ticket counters of the "last workgroup reduces" epilogues (gemm_core.h: tail_reduce_cols).
-   The counters must be ZERO when the region is first handed to the library (tfnas_hip.h) and are left zero by every launch. */
+   tiles; the last TFNAS_TAIL_SLOTS words are reserved (they held the ticket counters of the removed "last workgroup reduces"
+   epilogues; the size of the region is part of the workspace ABI and stays). */
 #define TFNAS_PART_ALLOC ((size_t)4 << 20)
 #define TFNAS_TAIL_SLOTS ((size_t)1024)
 #define TFNAS_PART_FLOATS (TFNAS_PART_ALLOC - TFNAS_TAIL_SLOTS)
-static inline unsigned* tail_counters(float* part) { return reinterpret_cast<unsigned*>(part + TFNAS_PART_FLOATS); }
-// tail epilogue of the depthwise kernels: cnt == nullptr -> partial rows only (a reduce launch follows); out = stats2 (forward)
-// or red1 (backward; cb1 != nullptr: also the BN1-backward table, what k_reduce_bn1 writes)
-struct DwTail {
-    unsigned* cnt;
-    double* out;
-    float* cb1;
-};
-// TFNAS_TAIL=1: the statistics partial rows of k_expand_fwd / k_project_fwd / the depthwise forward and backward kernels are
-// summed by the producer's last workgroup (tail_reduce.h) instead of a separate k_reduce_rows launch.  OFF by default --
-// measured: 4 of the 6-9 reduce launches per cell pass disappear, but the ticket (wait for the write-through stores + one
-// agent-scope atomic, paid by every workgroup) plus the winner's coherent read-back cost the producers what the tiny
-// launches cost (per-cell kernel time unchanged within 1 %, pair 74.6 -> 75.5 ms).
-static inline bool tail_enabled() {
-    static const int on = [] { const char* e = getenv("TFNAS_TAIL"); return (e && e[0] == '1') ? 1 : 0; }();
-    return on == 1;
-}
 int launch_bn1_consts(const TfnasCellDesc& d, const double* stats1, const double* red1, float* cb1,
                       hipStream_t s);
 

@@ -44,14 +44,11 @@ struct PathCtx {
     uint64_t ring[NRING], dxp;
     TfnasPathWs ws;
     hipStream_t side = nullptr;
-    hipStream_t side2 = nullptr;       // optional second weight-gradient stream (caller-supplied): odd cells go there
     bool own_side = true;              // false: the caller supplied the side stream (tfnas_path_set_side_stream)
     hipEvent_t fork[TFNAS_MAX_CELLS][3];
     hipEvent_t wdone[TFNAS_MAX_CELLS];
-    hipEvent_t join = nullptr, xfork = nullptr;
+    hipEvent_t join = nullptr;
     bool events_ok = false;
-    bool defer_join = false;           // tfnas_path_defer_join: tfnas_paths_bwd leaves the side stream(s) un-joined
-    bool join_pending = false;
 };
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -61,15 +58,6 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
         int _r = (call);        \
         if (_r != 0) return _r; \
     } while (0)
-
-// TFNAS_MERGE_FORKS=1: ONE fork per cell instead of three (cell_impl.h: CellSide::merged).  Off by default -- measured at
-// B = 128 (LAG = 3): 18.53 / 18.67 vs 18.43 / 18.55 ms per weight step: the 11-16 us a fork costs the data-gradient chain are
-// not on the critical path (the weight-gradient queue finishes last either way), and the later start of a cell's project /
-// depthwise weight gradients costs what the saved event records buy.
-bool forks_merged() {
-    static const int on = [] { const char* e = getenv("TFNAS_MERGE_FORKS"); return (e && e[0] == '1') ? 1 : 0; }();
-    return on == 1;
-}
 
 bool wgrad_side_enabled() {
     static int on = -1;
@@ -98,17 +86,12 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         nc += sg.ncell;
     }
     if (nc != pd.ncell) return TFNAS_EINVAL;
-    if (pd.dual != 0 && pd.dual != 1) return TFNAS_EINVAL;
-    // dual: both bi-sampling paths in one descriptor (sampled mode; the path input is shared, so the first stage's input
-    // cannot itself be a depth choice of two different paths)
-    if (pd.dual && (pd.soft || pd.efree_mask_lo || pd.stage[0].start_res == 0)) return TFNAS_EINVAL;
+    if (pd.reserved0 != 0) return TFNAS_EINVAL;          // (was `dual`: both bi-sampling paths in one descriptor; removed)
     // cells: chain the geometry, plan, size
     for (int i = 0; i < pd.ncell; ++i) {
         TfnasCellDesc& d = pd.cell[i];
         if (d.mode != TFNAS_MODE_CELL) return TFNAS_EINVAL;
-        if (!pd.soft && d.G != (pd.dual ? 2 : 1)) return TFNAS_EINVAL;   // a sampled path evaluates one candidate per cell
-        d.og = pd.dual ? 1 : 0;                                   // (dual: two, each with its own output ...
-        d.xg = (pd.dual && i > 0) ? 1 : 0;                        //  ... and, after the first cell, its own input)
+        if (!pd.soft && d.G != 1) return TFNAS_EINVAL;            // a sampled path evaluates one candidate per cell
         if (i > 0) {
             const TfnasCellDesc& p = pd.cell[i - 1];
             if (d.ic != p.oc) return TFNAS_EINVAL;
@@ -132,7 +115,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         }
     }
     // ---- arena layout.  First, at FIXED offsets (the same for every plan of this context, whatever widths it samples): the
-    // `part` scratch pieces -- their tails hold the ticket counters of the "last workgroup reduces" epilogues, which must
+    // `part` scratch pieces (kept at fixed offsets since round 2; nothing depends on it any more)
     // stay zero between launches (kernels.h), so they may never land on memory another plan used for something else.
     uint64_t off = 0;
     for (int k = 0; k < NSET; ++k) {
@@ -157,7 +140,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         const TfnasStage& sg = pd.stage[st];
         const TfnasCellDesc& l = pd.cell[sg.first_cell + sg.ncell - 1];
         StageOff& o = c.so[st];
-        o.count = (uint64_t)(pd.dual ? 2 : 1) * l.N * l.Ho * l.Wo * l.oc;
+        o.count = (uint64_t)l.N * l.Ho * l.Wo * l.oc;
         o.sink_out = ~(uint64_t)0;
         if (st + 1 < pd.nstage) { o.sink_out = off; off += up(o.count); }
         o.bw = off; off += ALIGN;
@@ -273,7 +256,6 @@ static int ensure_side(PathCtx* c) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wdone[i], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->xfork, hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;       // (a failed create leaks a few events; the process is unusable anyway)
     c->events_ok = true;
     return 0;
@@ -289,7 +271,6 @@ extern "C" int tfnas_path_destroy(void* ctx) {
             (void)hipEventDestroy(c->wdone[i]);
         }
         (void)hipEventDestroy(c->join);
-        (void)hipEventDestroy(c->xfork);
         if (c->own_side) (void)hipStreamDestroy(c->side);
     }
     delete c;
@@ -308,43 +289,11 @@ extern "C" int tfnas_path_set_side_stream(void* ctx, void* stream) {
     return 0;
 }
 
-// A second weight-gradient stream: the weight-gradient kernels of odd cells go there.  In the dual mode the data-gradient
-// chain of both bi-sampling paths is ONE queue and the weight-gradient kernels (leaves of the dependency graph, a third of
-// the step's kernel time) are what bounds the backward; two queues of them overlap their launch latencies.
-extern "C" int tfnas_path_set_side_stream2(void* ctx, void* stream) {
-    PathCtx* c = static_cast<PathCtx*>(ctx);
-    if (!c) return TFNAS_ENULL;
-    c->side2 = S(stream);
-    return 0;
-}
-
 static int join_sides(PathCtx* c, hipStream_t s) {
     hipError_t e = hipEventRecord(c->join, c->side);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join, 0);
-    if (e == hipSuccess && c->side2) {
-        e = hipEventRecord(c->xfork, c->side2);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->xfork, 0);
-    }
-    if (e != hipSuccess) {
-        (void)hipStreamSynchronize(c->side);
-        if (c->side2) (void)hipStreamSynchronize(c->side2);
-    }
-    c->join_pending = false;
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->side);
     return (int)e;
-}
-
-extern "C" int tfnas_path_defer_join(void* ctx, int on) {
-    PathCtx* c = static_cast<PathCtx*>(ctx);
-    if (!c) return TFNAS_ENULL;
-    c->defer_join = on != 0;
-    return 0;
-}
-
-extern "C" int tfnas_path_join(void* ctx, void* stream) {
-    PathCtx* c = static_cast<PathCtx*>(ctx);
-    if (!c) return TFNAS_ENULL;
-    if (!c->join_pending || !c->events_ok) return 0;
-    return join_sides(c, S(stream));
 }
 
 extern "C" int tfnas_path_plan(void* ctx, const TfnasPathDesc* pd, TfnasPathWs* ws) {
@@ -407,18 +356,13 @@ struct BwdRun {
     float *dx0, *dwmix, *dcell_lat;
     hipStream_t s;
     bool side_on;
-    bool merged;                 // one fork per cell (cell_impl.h: CellSide::merged)
-    PendingExpand pend;
 };
 
 // before cell i (or the sink step in front of it) reuses scratch set i % NSET and ring slot (i+1) % NRING, the
 // weight-gradient kernels of cell i + NSET -- the last ones that read them -- must be done (side stream, <= LAG cells behind)
 int wait_wgrads(BwdRun& r, int i) {
-    // (merged forks: cell j's expand weight gradient is launched inside cell j-1's call, so the event that covers ALL of cell
-    //  j's weight-gradient kernels is wdone[j - 1] -- later on the same stream than wdone[j])
-    const int j = i + NSET - (r.merged ? 1 : 0);
-    if (!r.side_on || j >= r.c->pd.ncell || j < 0 || !r.c->pd.cell[j].need_wgrad) return 0;
-    if (r.merged && j <= i) return 0;
+    const int j = i + NSET;
+    if (!r.side_on || j >= r.c->pd.ncell || !r.c->pd.cell[j].need_wgrad) return 0;
     return (int)hipStreamWaitEvent(r.s, r.c->wdone[j], 0);
 }
 
@@ -482,10 +426,8 @@ int bwd_cell(BwdRun& r, int i) {
     CellSide so = {};
     const bool side = r.side_on && pd.cell[i].need_wgrad;
     if (side) {
-        so.side = (c.side2 && (i & 1)) ? c.side2 : c.side;
+        so.side = c.side;
         for (int k = 0; k < 3; ++k) so.fork[k] = c.fork[i][k];
-        so.merged = r.merged;
-        so.pend = &r.pend;
     }
     TRY(cell_bwd_impl(pd.cell[i], c.cws[i], b, r.s, side ? &so : nullptr));
     if (side) HIP_TRY(hipEventRecord(c.wdone[i], so.side));
@@ -527,8 +469,6 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         for (int i = 0; i < c->pd.ncell; ++i) any_w = any_w || c->pd.cell[i].need_wgrad;
         r.side_on = wgrad_side_enabled() && any_w;
         if (r.side_on) TRY(ensure_side(c));
-        r.merged = r.side_on && forks_merged() && !c->side2;
-        r.pend.valid = false;
     }
     const PathCtx* c0 = run[0].c;
     int lat_off_end = 0;
@@ -543,26 +483,10 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         for (int j = sg.ncell - 1; j >= 0 && rc == 0; --j)
             for (int p = 0; p < npath && rc == 0; ++p) rc = bwd_cell(run[p], sg.first_cell + j);
     }
-    // merged forks: the last cell's expand weight gradient still waits for its fork
-    for (int p = 0; p < npath && rc == 0; ++p) {
-        BwdRun& r = run[p];
-        if (!r.merged || !r.pend.valid) continue;
-        hipError_t e = hipEventRecord(r.c->xfork, r.s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(r.c->side, r.c->xfork, 0);
-        if (e != hipSuccess) { rc = (int)e; break; }
-        rc = launch_pending_expand(r.pend, r.c->side);
-    }
-    // join every side stream (also on an error path: the caller frees / reuses the arena next) -- unless the caller asked to
-    // do that itself later (tfnas_path_defer_join): the weight gradients are leaves, only the optimizer step consumes them,
-    // and whatever the caller enqueues next on the path's stream (the stem's backward) need not wait for the last cells'
-    // weight-gradient kernels
+    // join every side stream (also on an error path: the caller frees / reuses the arena next)
     for (int p = 0; p < npath; ++p) {
         BwdRun& r = run[p];
         if (!r.side_on) continue;
-        if (r.c->defer_join && rc == 0) {
-            r.c->join_pending = true;
-            continue;
-        }
         const int e = join_sides(r.c, r.s);
         if (e != 0 && rc == 0) rc = e;
     }

@@ -111,25 +111,6 @@ __global__ __launch_bounds__(256) void k_mix_fwd(TfnasCellDesc d, const float* _
         tab[i] = make_float2(c.x, c.y * (wmix ? wmix[i / oc] : 1.f));
     }
     __syncthreads();
-    if (d.og) {
-        // every group has its own output (the two bi-sampling paths in one launch): out[g] = BN3(Pr[g]) (+ x[g])
-        const size_t per = (size_t)Po * OQ, tot = per * G;
-        for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * 256) {
-            const int g = (int)(idx / per);
-            const size_t r = idx - (size_t)g * per, p = r / OQ;
-            const int o = (int)(r % OQ) * 4;
-            const f32x4 pr = ld4(Pr + ((size_t)g * Po + p) * oc + o);
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 t = tab[g * oc + o + j];
-                v[j] = (pr[j] - t.x) * t.y;
-            }
-            if (d.has_res) v += ld4(x + ((d.xg ? (size_t)g * Po : 0) + p) * d.ic + o);
-            st4(out + ((size_t)g * Po + p) * oc + o, v);
-        }
-        return;
-    }
     const size_t total = (size_t)Po * OQ;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const size_t p = idx / OQ;
@@ -158,15 +139,7 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int oc = d.oc, TQ = oc >> 2, RP = 256 / TQ;
     const int Po = d.N * d.Ho * d.Wo;
-    // og = 1 (every group has its own output gradient): blockIdx.y = group, a G = 1 problem on that group's slices; the
-    // partial row keeps the [G*oc][2] | [oc] layout (the resdot part is not used in that mode)
-    const int gb = d.og ? (int)blockIdx.y : 0, G = d.og ? 1 : d.G, Gall = d.G;
-    if (d.og) {
-        dout += (size_t)gb * Po * oc;
-        Pr += (size_t)gb * Po * oc;
-        stats3 += 2 * (size_t)gb * oc;
-        if (d.xg) x += (size_t)gb * Po * d.ic;
-    }
+    const int G = d.G, Gall = d.G;
     float2* tab = reinterpret_cast<float2*>(lds);                    // [G*oc] (mean3, rstd3)
     f32x4* buf = reinterpret_cast<f32x4*>(lds + 2 * Gall * oc);      // [256]
     for (int i = threadIdx.x; i < G * oc; i += 256) tab[i] = bn_consts(stats3 + 2 * (size_t)i, 1.0 / (double)Po, d.eps);
@@ -196,10 +169,10 @@ __global__ __launch_bounds__(256) void k_mix_bwd_stats(TfnasCellDesc d, const fl
         }
     }
     // this workgroup's row of the partials matrix: [G*oc][2] (S1,S2) followed by [oc] partial <dout,x> sums
-    float* prow = part + (size_t)blockIdx.x * (2 * Gall * oc + oc) + 2 * (size_t)gb * oc;
+    float* prow = part + (size_t)blockIdx.x * (2 * Gall * oc + oc);
     s1 = reduce_rows(s1, buf, pr, oq, RP, TQ, active);
     sx = reduce_rows(sx, buf, pr, oq, RP, TQ, active);
-    if (active && pr == 0 && gb == 0) st4(prow + 2 * Gall * oc + o, sx);
+    if (active && pr == 0) st4(prow + 2 * Gall * oc + o, sx);
 #pragma unroll
     for (int g = 0; g < TFNAS_MAX_GROUPS; ++g) {
         if (g < G) {
@@ -686,10 +659,6 @@ int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const d
     return (int)hipGetLastError();
 }
 
-static int rq_mode() {
-    static const int v = getenv("TFNAS_REDUCE_Q") ? atoi(getenv("TFNAS_REDUCE_Q")) : 4;     // 0: the scalar kernels
-    return v;
-}
 int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, double* out_d, float* out_f,
                        hipStream_t s, int nbatch, size_t in_stride, size_t out_stride) {
     ProfScope _prof(TK_REDUCE_ROWS, s);
@@ -698,10 +667,7 @@ int launch_reduce_rows(const float* part, int nb, int ncols, size_t stride, doub
     if (al4 && nb <= 128 && ncols >= 1024)
         hipLaunchKernelGGL(k_reduce_rows_wide, dim3(cdiv(ncols, 128), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d,
                            out_f, in_stride, out_stride);
-    else if (al4 && nb > 64 && rq_mode() == 8)
-        hipLaunchKernelGGL(k_reduce_rows_q<8>, dim3(cdiv(ncols, 32), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
-                           in_stride, out_stride);
-    else if (al4 && nb > 64 && rq_mode() == 4)
+    else if (al4 && nb > 64)
         hipLaunchKernelGGL(k_reduce_rows_q<4>, dim3(cdiv(ncols, 16), nby), dim3(256), 0, s, part, nb, ncols, stride, out_d, out_f,
                            in_stride, out_stride);
     else if (ncols <= 2048 && nb > 256)
@@ -744,7 +710,7 @@ int launch_se_bwd_reduce(const TfnasCellDesc& d, const float* dZ, const float* D
 int launch_mix_fwd(const TfnasCellDesc& d, const float* Pr, const double* stats3, const float* wmix,
                    const float* x, float* out, hipStream_t s) {
     ProfScope _prof(TK_MIX_FWD, s);
-    const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4) * (d.og ? d.G : 1);
+    const size_t total = (size_t)d.N * d.Ho * d.Wo * (d.oc / 4);
     size_t blocks = cdiv64(total, 256 * 4);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -765,7 +731,7 @@ int launch_mix_bwd_stats(const TfnasCellDesc& d, const float* dout, const float*
     if (rpb < 8 * RP) rpb = 8 * RP;
     const size_t shm = (size_t)(2 * d.G * d.oc + 4 * 256) * sizeof(float);
     const int gx = cdiv(Po, rpb);
-    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx, d.og ? d.G : 1), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
+    hipLaunchKernelGGL(k_mix_bwd_stats, dim3(gx), dim3(256), shm, s, d, dout, Pr, stats3, x, part, rpb);
     _prof.stop();
     return launch_reduce_rows(part, gx, ncols, (size_t)ncols, red3, nullptr, s);
 }
@@ -803,9 +769,7 @@ int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, con
     ProfScope _prof(TK_SE_BWD_REDUCE, s);
     // 32-channel chunks (one 128-byte line per pixel) where 64-channel ones leave the chip under-filled: the sampled launches
     // of the 112 x 112 ... 28 x 28 cells are N x (1..4) workgroups of 0.2-1.6 MB each
-    static const int ch_env = getenv("TFNAS_BN2POOL_CH") ? atoi(getenv("TFNAS_BN2POOL_CH")) : 0;
-    int CH = (d.N * chunk_count(d, 64, false) < 1024 && d.Ho * d.Wo >= 196) ? 32 : 64;
-    if (ch_env == 32 || ch_env == 64) CH = ch_env;
+    const int CH = (d.N * chunk_count(d, 64, false) < 1024 && d.Ho * d.Wo >= 196) ? 32 : 64;
     dim3 grid(d.N, chunk_count(d, CH, false));
     ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_bn2_pool<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, dgate, pp, CH); })
     return (int)hipGetLastError();

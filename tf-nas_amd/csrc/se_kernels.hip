@@ -10,6 +10,7 @@
 //   MODE 3  dpool[N,mc] = dhpre[N,se] W_r                                            (NN)
 //   MODE 4  g_se_e[mc,se] = dgl^T act(hpre)                                          (TN, K = batch)
 //   MODE 5  g_se_r[se,mc] = (pooled^T dhpre)^T                                       (TN, K = batch)
+#include <cstring>
 #include "gemm_core.h"
 #include "kernels.h"
 #include "prof.h"
@@ -585,9 +586,17 @@ __global__ __launch_bounds__(256) void k_se_nn(TfnasCellDesc d, SeArgs a) {
 }
 
 // the wave-level kernels need aligned float4 rows of W_r / the gradients: every SE group's mid width a multiple of 4
+// TFNAS_SE = wave (default: wave-level MFMA kernels where the shapes allow) | fused (per-image kernels) | gemm (LDS-tiled GEMMs):
+// the three formulations of the excite FCs, every one compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
+static int se_variant() {
+    static const int v = [] {
+        const char* e = getenv("TFNAS_SE");
+        return !e ? 0 : !strcmp(e, "fused") ? 1 : !strcmp(e, "gemm") ? 2 : 0;
+    }();
+    return v;
+}
 static bool se_wave_ok(const TfnasCellDesc& d) {
-    static const int on = [] { const char* e = getenv("TFNAS_SE_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!on) return false;
+    if (se_variant() != 0) return false;
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].se > 0 && ((d.g[g].mc & 3) || (d.g[g].se & 3) || d.g[g].mc < 4)) return false;
     return true;
@@ -622,13 +631,12 @@ static int se_ksplit(const TfnasCellDesc& d, int mcp_max, size_t cap) {
     return ks < 1 ? 1 : ks;
 }
 
-// the fused per-image kernels need the pooled row + hidden vectors in LDS; TFNAS_SE_GEMM=1 keeps the GEMM path (A/B, tests)
+// the fused per-image kernels need the pooled row + hidden vectors in LDS
 static size_t se_fused_lds(int mcp_max, int se_max) {
     return (size_t)(((mcp_max + 3) & ~3) + ((se_max + 3) & ~3) + 256 + SE_CH * (se_max | 1)) * sizeof(float);
 }
 static bool se_fused_ok(int mcp_max, int se_max) {
-    static const char* e = getenv("TFNAS_SE_GEMM");
-    if (e && e[0] == '1') return false;
+    if (se_variant() == 2) return false;
     return se_max <= 256 && se_fused_lds(mcp_max, se_max) <= 60 * 1024;
 }
 

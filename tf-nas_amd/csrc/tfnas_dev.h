@@ -87,11 +87,6 @@ __device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int) { r
 __device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int) { st4(base + idx, v); }
 __device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int) { st4_nt(base + idx, v); }
 
-// agent-scope (write-through) store of a value another workgroup of the same launch reads back (gemm_core.h: tail_reduce_cols)
-__device__ __forceinline__ void st_coherent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x4 splat4(float a) { f32x4 z = {a, a, a, a}; return z; }
 

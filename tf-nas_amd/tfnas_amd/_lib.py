@@ -31,7 +31,7 @@ class TfnasCellDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
                                           'Ho', 'Wo', 'M', 'SE')]
                 + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
-                   ('stor', C.c_int32), ('xg', C.c_int32), ('og', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+                   ('stor', C.c_int32), ('reserved0', C.c_int32), ('reserved1', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
 
 
 class TfnasCellWs(C.Structure):
@@ -50,7 +50,7 @@ class TfnasStage(C.Structure):
 
 
 class TfnasPathDesc(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'nstage', 'soft', 'need_dx0', 'efree_mask_lo', 'dual')]
+    _fields_ = ([(n, C.c_int32) for n in ('ncell', 'nstage', 'soft', 'need_dx0', 'efree_mask_lo', 'reserved0')]
                 + [('stage', TfnasStage * MAX_STAGES), ('cell', TfnasCellDesc * MAX_CELLS)])
 
 
@@ -83,10 +83,7 @@ _PROTOS = {
     'tfnas_path_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'tfnas_path_destroy': (C.c_int, [C.c_void_p]),
     'tfnas_path_set_side_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
-    'tfnas_path_set_side_stream2': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_set_stats_sync': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
-    'tfnas_path_defer_join': (C.c_int, [C.c_void_p, C.c_int]),
-    'tfnas_path_join': (C.c_int, [C.c_void_p, C.c_void_p]),
     'tfnas_path_plan': (C.c_int, [C.c_void_p, C.POINTER(TfnasPathDesc), C.POINTER(TfnasPathWs)]),
     'tfnas_paths_fwd': (C.c_int, [C.c_int] + [_PP] * 8),
     'tfnas_paths_bwd': (C.c_int, [C.c_int] + [_PP] * 11 + [C.c_int, C.c_int]),
@@ -132,7 +129,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)        # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if l.tfnas_abi_version() != 1:
+        if l.tfnas_abi_version() != 2:
             raise RuntimeError('tfnas_amd: ABI version mismatch')
         for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs, TfnasBnAffine)):
             if l.tfnas_sizeof(which) != C.sizeof(st):

@@ -17,12 +17,12 @@ from . import _lib
 from ._lib import TfnasCellDesc, TfnasCellWs, ptr, ptr_array, check
 
 BN_EPS = 1e-5
-# TFNAS_EFREE=0 keeps the expanded tensor E in every cell (A/B timing, equivalence tests)
-EFREE = os.environ.get('TFNAS_EFREE', '1') != '0'
-# default policy: stride-2 cells with ic <= 24 (cells 0 and 2 of the supernet, -25 % / -16 % of their alpha-step time).
-# The library also supports stride 1 and ic = 40, where the row-streaming kernels on a materialised E are still faster;
-# TFNAS_EFREE_STRIDE1=1 takes E-free wherever it is supported (tests).
-EFREE_STRIDE1 = os.environ.get('TFNAS_EFREE_STRIDE1', '0') == '1'
+# TFNAS_EFREE = 1 (default policy: stride-2 cells with ic <= 24 -- cells 0 and 2 of the supernet, -25 % / -16 % of their alpha-step
+# time) | 0 (the expanded tensor E is kept in every cell: A/B timing, equivalence tests) | all (E-free wherever the library
+# supports it -- stride 1 and ic = 40 too, where the row-streaming kernels on a materialised E are still faster: tests)
+_EFREE_ENV = os.environ.get('TFNAS_EFREE', '1')
+EFREE = _EFREE_ENV != '0'
+EFREE_STRIDE1 = _EFREE_ENV == 'all'
 
 
 def _stream(dev):

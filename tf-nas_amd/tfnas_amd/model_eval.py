@@ -193,8 +193,8 @@ class CrossEntropyLabelSmooth(nn.Module):
 
 # TFNAS_RETRAIN_DIRECT=0: the blocks return gradient temporaries and autograd adds them into the arena (one launch per parameter);
 # TFNAS_RETRAIN_LAZY=0: every block joins its weight-gradient kernels before it returns.
-DIRECT_GRADS = os.environ.get('TFNAS_RETRAIN_DIRECT', '1') != '0'
-LAZY_JOIN = os.environ.get('TFNAS_RETRAIN_LAZY', '1') != '0'
+DIRECT_GRADS = True          # (tests flip these two module flags to compare with the plain route)
+LAZY_JOIN = True
 
 
 class RetrainState:
@@ -215,10 +215,22 @@ class RetrainState:
         return self.arena.intact()
 
     @staticmethod
-    def fusable(opt):
+    def fusable(opt, model=None):
+        """The fused tail updates EVERY parameter of the arena with one set of hyper-parameters, so it stands in for
+        ``optimizer.step()`` only when that is what the optimizer would do: a plain SGD with ONE param group that holds exactly
+        the model's parameters, all of them trainable, and no step hooks registered (they would never run).  Anything else --
+        frozen parameters, a subset, per-group rates, hooks -- takes torch's clip_grad_norm_ + optimizer.step()."""
         g = opt.param_groups
-        return (isinstance(opt, torch.optim.SGD) and len(g) == 1 and not g[0].get('nesterov') and not g[0].get('dampening')
-                and not g[0].get('maximize'))
+        if not (isinstance(opt, torch.optim.SGD) and len(g) == 1 and not g[0].get('nesterov') and not g[0].get('dampening')
+                and not g[0].get('maximize')):
+            return False
+        if getattr(opt, '_optimizer_step_pre_hooks', None) or getattr(opt, '_optimizer_step_post_hooks', None):
+            return False
+        if model is not None:
+            mine = list(model.parameters())
+            if not all(p.requires_grad for p in mine) or {id(p) for p in g[0]['params']} != {id(p) for p in mine}:
+                return False
+        return True
 
     def _bind_momentum(self, opt):
         a = self.arena
@@ -278,6 +290,10 @@ class RetrainState:
                                                   float(hp['lr']), float(hp['momentum']), float(hp['weight_decay']), float(scale),
                                                   _lib.ptr(self._scratch), self._scratch.numel(), _lib.ptr(self._gnorm), stream),
                    'tfnas_sgd_clip_step')
+        # what optimizer.step() would have recorded: learning-rate schedulers check these before their own step()
+        if hasattr(opt, '_step_count'):
+            opt._step_count += 1
+        opt._opt_called = True
 
 
 def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None, fused=True):
@@ -288,7 +304,7 @@ def train_step(model, x, target, criterion, optimizer, grad_clip=5.0, group=None
     import torch.distributed as dist
     model.train()
     st = None
-    if fused and x.is_cuda and RetrainState.fusable(optimizer):
+    if fused and x.is_cuda and RetrainState.fusable(optimizer, model):
         st = getattr(model, '_retrain_state', None)
         if st is None or not st.intact():
             st = RetrainState(model)

@@ -142,34 +142,12 @@ class PathRunner:
         except Exception:
             pass
 
-    # ---- deferred join of the weight-gradient streams ------------------------------------------------------------------
-    def defer_joins(self, names, on):
-        """tfnas_path_defer_join for the slots ``names`` (created on demand)."""
-        for n in names:
-            s = self._slot(n)
-            if getattr(s, 'deferred', False) != bool(on):
-                check(self.lib.tfnas_path_defer_join(s.ctx, int(bool(on))), 'tfnas_path_defer_join')
-                s.deferred = bool(on)
-
-    def join(self, names, streams):
-        """Join the weight-gradient streams of the slots ``names`` to ``streams`` (one per slot) -- before the optimizer step."""
-        for n, st in zip(names, streams):
-            s = self._slots.get(n)
-            if s is not None and getattr(s, 'deferred', False):
-                check(self.lib.tfnas_path_join(s.ctx, C.c_void_p(st.cuda_stream)), 'tfnas_path_join')
-
     # ---- descriptor templates ---------------------------------------------------------------------------------
     def _template(self, ci, idx, N, H, W):
-        """Planned TfnasCellDesc of cell ``ci`` with candidate ``idx`` (None: all 8; a pair: the two bi-sampling candidates
-        of the dual mode, one group each), weight / gradient pointers bound."""
+        """Planned TfnasCellDesc of cell ``ci`` with candidate ``idx`` (None: all 8), weight / gradient pointers bound."""
         cell = self.cells[ci]
         key = (ci, idx, N, H, W)
-        if idx is None:
-            blocks = list(cell.m_ops)
-        elif isinstance(idx, tuple):
-            blocks = [cell.m_ops[i] for i in idx]
-        else:
-            blocks = [cell.m_ops[idx]]
+        blocks = list(cell.m_ops) if idx is None else [cell.m_ops[idx]]
         t = self._tmpl.get(key)
         if t is not None and t.g[0].w_expand == blocks[0].inverted_bottleneck.conv.weight.data_ptr():
             return t
@@ -202,22 +180,15 @@ class PathRunner:
         if ws is not None and getattr(s, 'side', None) is not ws:
             check(self.lib.tfnas_path_set_side_stream(s.ctx, C.c_void_p(ws.cuda_stream)), 'tfnas_path_set_side_stream')
             s.side = ws
-        ws2 = self.wgrad_streams.get(name + '2')
-        if ws2 is not None and getattr(s, 'side2', None) is not ws2:
-            check(self.lib.tfnas_path_set_side_stream2(s.ctx, C.c_void_p(ws2.cuda_stream)), 'tfnas_path_set_side_stream2')
-            s.side2 = ws2
         return s
 
     def _plan(self, name, idxs, x0h, need_wgrad, need_dx0, need_dbetas):
-        """Fill and plan slot ``name`` for candidates ``idxs`` (None: soft mode; a list of pairs: dual mode, both bi-sampling
-        paths in one descriptor)."""
+        """Fill and plan slot ``name`` for candidates ``idxs`` (None: soft mode)."""
         s = self._slot(name)
         N, H, W, _ = x0h.shape
         soft = idxs is None
-        dual = (not soft) and isinstance(idxs[0], tuple)
         pd = s.pd
         pd.ncell, pd.nstage, pd.soft, pd.need_dx0 = len(self.cells), len(self.stages), int(soft), int(need_dx0)
-        pd.dual = int(dual)
         mask = 0
         h, w = H, W
         for i, cell in enumerate(self.cells):
@@ -247,10 +218,9 @@ class PathRunner:
             if not soft:
                 # size the arena for the widest candidate of every cell once, instead of growing it (device sync + GBs of
                 # hipMalloc) whenever a step samples a wider sub-network than any before
-                def widest(c, n):
-                    order = sorted(range(len(c.m_ops)), key=lambda i: (c.m_ops[i].mid_channels, c.m_ops[i].se_channels))
-                    return order[-1] if n == 1 else tuple(order[-2:])
-                wide = [widest(c, 2 if dual else 1) for c in self.cells]
+                def widest(c):
+                    return max(range(len(c.m_ops)), key=lambda i: (c.m_ops[i].mid_channels, c.m_ops[i].se_channels))
+                wide = [widest(c) for c in self.cells]
                 if list(idxs) != wide:
                     need = max(need, self._sampled_need(name, wide, x0h, need_wgrad, need_dx0))
                     return self._plan_with_arena(name, idxs, x0h, need_wgrad, need_dx0, need_dbetas, need)
@@ -264,7 +234,7 @@ class PathRunner:
         if s.arena is not None:
             torch.cuda.synchronize(self.device)             # (pending kernels may still use the old arena)
         s.arena = None
-        s.arena = torch.zeros(int(need * 1.02) + 1024, device=self.device, dtype=torch.float32)   # zero: ticket counters (tfnas_hip.h)
+        s.arena = torch.zeros(int(need * 1.02) + 1024, device=self.device, dtype=torch.float32)
 
     def _sampled_need(self, name, wide, x0h, need_wgrad, need_dx0):
         tmp = '_size_probe'
@@ -273,7 +243,6 @@ class PathRunner:
         N, H, W, _ = x0h.shape
         pd = s.pd
         pd.ncell, pd.nstage, pd.soft, pd.need_dx0, pd.efree_mask_lo = len(self.cells), len(self.stages), 0, int(need_dx0), 0
-        pd.dual = int(isinstance(wide[0], tuple))
         h, w = H, W
         for i, cell in enumerate(self.cells):
             pd.cell[i] = self._template(i, wide[i], N, h, w)
@@ -337,14 +306,6 @@ class PathRunner:
         """Both bi-sampling paths of a weight step, interleaved on the current stream and ``side_stream``."""
         idx_a, idx_b = tuple(int(i) for i in idx_a), tuple(int(i) for i in idx_b)
         return BiPathFn.apply(self, x0, idx_a, idx_b, side_stream, self._wants_wgrad(idx_a))
-
-    def dual(self, x0, idx_a, idx_b):
-        """Both bi-sampling paths of a weight step through ONE launch per kernel (TfnasPathDesc.dual): every cell carries the
-        two sampled candidates as two groups with their own inputs / outputs.  Returns (out_a, out_b)."""
-        pairs = tuple((int(a), int(b)) for a, b in zip(idx_a, idx_b))
-        if any(a == b for a, b in pairs):
-            raise ValueError('dual mode needs two different candidates per cell (bi-sampling never repeats one)')
-        return DualPathFn.apply(self, x0, pairs, self._wants_wgrad([a for a, _ in pairs]))
 
 
 def _out_tensor(s, N, dev):
@@ -433,7 +394,6 @@ class OnePathFn(torch.autograd.Function):
         else:
             runner._bwd(*args)
         if ctx.expose is not None and ctx.need_w:
-            runner.join([ctx.name], [cur])            # (a slot a search.w_step left in deferred-join mode: join now)
             ctx.expose.expose_weight_grads([ctx.idxs], track=False)
         return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None, None
 
@@ -491,42 +451,3 @@ class BiPathFn(torch.autograd.Function):
         if want_dx:
             dx = (dxa + dxb).permute(0, 3, 1, 2)
         return None, dx, None, None, None, None
-
-
-class DualPathFn(torch.autograd.Function):
-    """Both bi-sampling paths of a weight step (train_search.py:375-379) as ONE path whose cells carry the two sampled
-    candidates as two groups (TfnasPathDesc.dual): one launch per kernel for both paths -- twice the workgroups per launch,
-    half the launches, one dependency chain on one stream (+ the weight-gradient side stream)."""
-
-    @staticmethod
-    def forward(ctx, runner, x0, pairs, need_w):
-        _require_cuda(x0, 'path input')
-        x0h = _nhwc(x0)
-        dev = x0h.device
-        s = runner._plan('AB', list(pairs), x0h, need_w, ctx.needs_input_grad[1], False)
-        N = x0h.shape[0]
-        out = torch.empty((2, N, s.ws.out_h, s.ws.out_w, s.ws.out_c), device=dev, dtype=torch.float32)
-        cur = torch.cuda.current_stream(dev)
-        runner._fwd([s], [x0h], [None], [None], [out], [None], [cur])
-        ctx.runner, ctx.slot, ctx.gen = runner, s, s.gen
-        ctx.save_for_backward(x0h)
-        return out[0].permute(0, 3, 1, 2), out[1].permute(0, 3, 1, 2)
-
-    @staticmethod
-    def backward(ctx, da, db):
-        runner, s = ctx.runner, ctx.slot
-        _check_gen(s, ctx.gen)
-        x0h, = ctx.saved_tensors
-        dev = x0h.device
-        cur = torch.cuda.current_stream(dev)
-        dout = torch.stack([_nhwc(da), _nhwc(db)])               # [2][N][H][W][C] contiguous
-        dx0 = torch.empty_like(x0h) if s.pd.need_dx0 else None
-        args = ([s], [x0h], [None], [None], [dout], [None], [dx0], [None], [None], [cur])
-        hook, k = runner.segment_hook, runner.split_stage
-        if hook is not None and 0 < k < len(runner.stages):
-            runner._bwd(*args, stage_begin=k, stage_end=-1)
-            hook(cur, None)
-            runner._bwd(*args, stage_begin=0, stage_end=k)
-        else:
-            runner._bwd(*args)
-        return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None

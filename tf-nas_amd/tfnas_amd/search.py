@@ -27,7 +27,7 @@ def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-
     """train_search.py:197-206."""
     params = model.weight_parameters()
     # one fused kernel per chunk of tensors instead of three multi-tensor passes (weight decay, momentum, update)
-    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get('TFNAS_FUSED_OPT', '1') != '0'
+    fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
     opt_w = torch.optim.SGD(params, lr=w_lr, momentum=w_mom, weight_decay=w_wd, **({'fused': True} if fused else {}))
     # Zero momentum buffers up front.  torch's multi-tensor SGD falls back to two tiny per-tensor kernels for EVERY
     # parameter of a step as soon as one of them has no buffer yet -- which, with a freshly sampled sub-network per
@@ -390,10 +390,7 @@ class SearchState:
         return self._side_stream
 
     def _wgrad_map(self):
-        m = {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1], 'AB': self._wgrad_streams[0]}
-        if DUAL_WGRAD_STREAMS >= 2:
-            m['AB2'] = self._wgrad_streams[1]       # dual mode: odd cells' weight-gradient kernels on a second queue
-        return m
+        return {'A': self._wgrad_streams[0], 'B': self._wgrad_streams[1]}
 
     def _pick_streams(self, device):
         """The three extra streams of a w-step -- path B and the two weight-gradient streams -- are chosen by MEASURED
@@ -492,20 +489,7 @@ FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
 # data parallel: reduce the late stages' gradients while the early stages' backward is still running (SearchState.dp_begin)
 OVERLAP_ALLREDUCE = os.environ.get('TFNAS_OVERLAP_ALLREDUCE', '1') != '0'
 # choose the w-step's side streams by measured concurrency (streams.py); 0: first streams torch / the library hand out
-PICK_STREAMS = os.environ.get('TFNAS_PICK_STREAMS', '1') != '0'
-# w-step: 1 = both bi-sampling paths as two groups of ONE path descriptor (TfnasPathDesc.dual: one launch per kernel for both
-# paths, one dependency chain + the weight-gradient queue(s)); 0 (default) = two interleaved paths on two streams + two
-# weight-gradient streams (round 2).  Measured at B = 128 on one MI355X: the dual mode cuts the summed
-# kernel time of a pair from 147 to 103 ms and the launches of a w-step from ~1500 to ~1000, but the step gets LONGER (20.3 vs
-# 19.1 ms): it is bound by the length of ONE chain of ~1000 dependent launches + the weight-gradient queue, and with the two
-# paths merged nothing overlaps that chain's per-launch latencies any more.
-DUAL_PATHS = os.environ.get('TFNAS_DUAL', '0') == '1'
-# w-step: 1 = join the weight-gradient streams right before the optimizer step instead of at the end of the path's backward, so
-# that the stem's backward overlaps with the last cells' weight-gradient kernels.  Measured at B = 128: no effect (18.57 vs
-# 18.43-18.47 ms per w-step, pair unchanged: the stem's backward then shares the chip with those kernels) -- off by default.
-DEFER_JOIN = os.environ.get('TFNAS_DEFER_JOIN', '0') == '1'
-HEADS_ON_MAIN = os.environ.get('TFNAS_HEADS_ON_MAIN', '1') == '1'
-DUAL_WGRAD_STREAMS = int(os.environ.get('TFNAS_DUAL_WGRAD_STREAMS', '2'))     # weight-gradient queues of the dual mode (1 or 2)
+PICK_STREAMS = True
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
 # run the RCCL all-reduce path even at world_size 1 (tests/test_gpu_dist.py: 1-rank torchrun must equal the plain run)
@@ -696,40 +680,20 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         c.last_idx = ia
     if fused:
         state.dp_begin([idx_a] if idx_b is None else [idx_a, idx_b], group)
-    # the path's backward leaves its weight-gradient streams un-joined (they are joined right before the optimizer step
-    # below), so the stem's backward overlaps with the last cells' weight-gradient kernels -- not with a gradient all-reduce
-    # hook armed (it packs the late stages' gradients between the two backward segments)
-    slots = (['AB'] if DUAL_PATHS else ['A', 'B']) if bi_sampling else ['A']
-    runner.defer_joins(slots, DEFER_JOIN and fused and runner.segment_hook is None)
-    if bi_sampling and DUAL_PATHS:
-        # both paths through one launch per kernel (TfnasPathDesc.dual), everything on the current stream
-        state.side_stream(dev)                  # (picks the weight-gradient side stream on first use)
-        oa, ob = runner.dual(feat, idx_a, idx_b)
-        logits_g = model.classifier(model._head(oa))
-        loss = F.cross_entropy(logits_g, target) + F.cross_entropy(model.classifier(model._head(ob)), target)
-    elif bi_sampling:
+    if bi_sampling:
         cur = torch.cuda.current_stream(dev)
         side = state.side_stream(dev)
         oa, ob = runner.bisampled(feat, idx_a, idx_b, side)
         logits_g = model.classifier(model._head(oa))
         loss = F.cross_entropy(logits_g, target)
-        if HEADS_ON_MAIN:
-            # both heads on the current stream: the shared head / classifier parameters then accumulate their two gradients on
-            # the stream their AccumulateGrad nodes live on (no cross-stream accumulation, no autograd warning about it)
-            cur.wait_stream(side)
-            loss = loss + F.cross_entropy(model.classifier(model._head(ob)), target)
-        else:
-            with torch.cuda.stream(side):
-                loss_r = F.cross_entropy(model.classifier(model._head(ob)), target)
-            cur.wait_stream(side)
-            loss_r.record_stream(cur)
-            loss = loss + loss_r
+        # both heads on the current stream: the shared head / classifier parameters then accumulate their two gradients on
+        # the stream their AccumulateGrad nodes live on (no cross-stream accumulation, no autograd warning about it)
+        cur.wait_stream(side)
+        loss = loss + F.cross_entropy(model.classifier(model._head(ob)), target)
     else:
         logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
         loss = F.cross_entropy(logits_g, target)
     loss.backward()
-    cur = torch.cuda.current_stream(dev)
-    runner.join(slots, [cur] * len(slots))      # (no-op unless deferred: everything below reads the weight gradients)
     idx_lists = [idx_a] if idx_b is None else [idx_a, idx_b]
     if FUSED_OPT and state._fusable_sgd(opt_w):
         if state.expose_grads:

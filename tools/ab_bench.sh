@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: A/B of environment settings on ONE box (same clocks): each argument is an env assignment list, e.g.
-#   gpurun -- 'bash tools/ab_bench.sh tag "TFNAS_DUAL=0" "TFNAS_DUAL=1 TFNAS_DUAL_WGRAD_STREAMS=1" "TFNAS_DUAL=1"'
+#   gpurun -- 'bash tools/ab_bench.sh tag "TFNAS_GEMM=f32" "TFNAS_GEMM=x3"'
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 """Stress: row-streaming vs tiled depthwise kernels on odd shapes (run once per variant, compare the saved tensors):
-  python tools/stress_stream_vs_tiled.py a.pt ; TFNAS_DW_TILED=1 python tools/stress_stream_vs_tiled.py b.pt"""
+  python tools/stress_stream_vs_tiled.py a.pt ; TFNAS_DW=tiled python tools/stress_stream_vs_tiled.py b.pt"""
 import os, sys
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 for p in ('', 'tf-nas_amd', 'oracle', 'tests'):
