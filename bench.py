@@ -403,6 +403,18 @@ def run_gpu(args):
     torch.cuda.synchronize()
     w_ms = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs) / (2 * nsplit)
     a_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / nsplit
+    # multi-GPU self-evidence: how many ranks the first collective really spanned, and every rank's own
+    # step times (a straggler or a rank on a colliding hardware queue shows up as spread here, not only in the max-over-ranks time)
+    dist_info = None
+    if dist.is_initialized():
+        mine = torch.tensor([w_ms, a_ms, float(rank)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        rows = sorted((int(t[2]), float(t[0]), float(t[1])) for t in allr)
+        dist_info = dict(backend=dist.get_backend(), rccl_ranks=dist.get_world_size(), ranks_seen=[r for r, _, _ in rows],
+                         w_step_ms_per_rank=[round(w, 3) for _, w, _ in rows], a_step_ms_per_rank=[round(a, 3) for _, _, a in rows],
+                         w_step_ms_spread=round(max(w for _, w, _ in rows) - min(w for _, w, _ in rows), 3),
+                         gpu_max_hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'))
 
     # ---- the reference-style loop on the drop-in model (world 1 only: it has no gradient all-reduce)
     dropin = None
@@ -511,11 +523,15 @@ def run_gpu(args):
                                            'train_search.py:366-426) on ImageNet-100-shaped 224x224 batches, '
                                            'initial widths, T=5, target_lat=15 (BASELINE configs[1] geometry, fp32)',
                                   batch_per_gpu=B, global_batch=B * world, train_images_per_step=2 * B * world,
-                                  parallelism='dp%d' % world),
+                                  parallelism='dp%d' % world,
+                                  gemm_arithmetic={0: 'fp32 MFMA', 1: 'bf16 MFMA (reduced precision)', 3: 'split-bf16 x2',
+                                                   6: 'split-bf16 x3 MFMA: every fp32 operand as three bf16 planes, fp32 '
+                                                      'accumulation (fp32-accurate products; the oracle tolerance is unchanged)'
+                                                   }.get(int(lib.tfnas_gemm_mode()) & 0xff, str(lib.tfnas_gemm_mode()))),
                       roofline=roof, w_step_ms=round(w_ms, 3), a_step_ms=round(a_ms, 3),
                       all_images_per_s=round(3.0 * B * world * args.steps / dt, 2),
                       dropin_images_per_s=None if dropin is None else round(dropin, 2), width_sweep=sweep,
-                      retrain=retrain,
+                      retrain=retrain, dist=dist_info,
                       kernel_ms_per_pair={k: round(v[1], 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1][1])
                                           if v[0]},
                       kernel_roofline=kernel_roofline(fam_ms, B))

@@ -170,7 +170,7 @@ def test_fused_step_only_stands_in_for_an_optimizer_that_updates_every_parameter
     with warnings.catch_warnings():
         warnings.simplefilter('error')                      # ("lr_scheduler.step() before optimizer.step()" would raise here)
         sched.step()
-    frozen = m.classifier.weight
+    frozen = next(m.classifier.parameters())
     frozen.requires_grad_(False)
     before = frozen.detach().clone()
     sub = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], 0.05, momentum=0.9, weight_decay=4e-5)

@@ -52,16 +52,27 @@ def test_three_epochs_with_width_remasking(tmp_path):
 
 
 def test_lut_builder_measures_monotone_plausible_latencies(tmp_path):
-    """tfnas_amd/lut_builder.py on the GPU: a few keys, coarse width step; the table drops into Network and get_lookup_latency."""
-    from tfnas_amd import lut_builder, geometry as g
-    from tfnas_amd.latency import load_lat_lookup, get_lookup_latency
+    """tfnas_amd/lut_builder.py on the GPU: a few keys, coarse width step, both meanings of the table -- 'inference' (eval-mode
+    affine BatchNorm through tfnas_mbconv_fwd: the reference's meaning, make_lat_lut_example.py:44-492 + tools/utils.py:12-34) and
+    'search' (the search net's batch-statistic forward).  Every return code inside the timed loops is checked by the builder; the
+    tables drop into Network / get_lookup_latency; latency grows with the width; the inference forward (no batch reductions) is
+    not slower than the training-mode one."""
+    from tfnas_amd import lut_builder
+    from tfnas_amd.latency import load_lat_lookup
     keys = [kv for kv in lut_builder.lut_keys() if kv[0].startswith('MBInvertedResBlock_14_112_') or '_7_192_' in kv[0]]
-    lut = lut_builder.build_latency_lookup(step=224, iters=5, keys=keys)
-    assert 0.01 < lut['base'] < 50.0
-    for key, gm in keys:
-        tab = lut[key]
-        assert len(tab) == gm['max_mc'] and all(0.0 < v < 100.0 for v in tab.values())
-        assert tab[gm['max_mc']] > 0.5 * tab[gm['ic'] + 1]          # wider is not dramatically cheaper
+    luts = {}
+    for mode in ('inference', 'search'):
+        lut = luts[mode] = lut_builder.build_latency_lookup(step=224, iters=5, keys=keys, mode=mode)
+        assert 0.01 < lut['base'] < 50.0
+        for key, gm in keys:
+            tab = lut[key]
+            assert len(tab) == gm['max_mc'] and all(0.0 < v < 100.0 for v in tab.values())
+            assert tab[gm['max_mc']] > 0.5 * tab[gm['ic'] + 1]          # wider is not dramatically cheaper
+            ws = sorted(tab)
+            assert all(tab[a] <= tab[b] * 1.5 + 1e-3 for a, b in zip(ws, ws[1:]))    # piecewise-linear, no wild dips
+    tot = {m: sum(luts[m][k][gm['max_mc']] for k, gm in keys) for m in luts}
+    assert tot['inference'] <= 1.15 * tot['search'], tot
+    lut = luts['inference']
     p = str(tmp_path / 'lut.npz')
     lut_builder.save_lat_lookup(lut, p)
     back = load_lat_lookup(p)

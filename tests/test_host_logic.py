@@ -134,6 +134,22 @@ def test_parsing_known_answers_and_lut_builder_key_set(tmp_path):
     assert back['base'] == 1.5 and back[keys[0]][8] == small[keys[0]][8]
 
 
+def test_shipped_mi355x_table_is_the_inference_table():
+    """data/latency_mi355x.npz (round 4): inference latency of the derived blocks (eval-mode affine BatchNorm), the reference's
+    meaning; rounds 2-3's training-forward table is kept as 'mi355x_search'.  Same key set and dense width range as the reference's
+    tables; no block is slower in inference than in the search net's batch-statistic forward (measured on the same GPU type)."""
+    from tfnas_amd import lut_builder
+    from tfnas_amd.latency import load_lat_lookup
+    inf, srch, ref = load_lat_lookup('mi355x'), load_lat_lookup('mi355x_search'), load_lat_lookup('gpu')
+    assert set(inf) == set(srch) == set(ref) and 0.0 < inf['base'] < srch['base'] * 1.2
+    slower = 0
+    for k, gm in lut_builder.lut_keys():
+        assert len(inf[k]) == gm['max_mc'] and all(v > 0.0 for v in inf[k].values())
+        assert inf[k][gm['max_mc']] >= inf[k][gm['ic'] + 1] * 0.8               # latency does not fall with the width
+        slower += inf[k][gm['max_mc']] > 1.1 * srch[k][gm['max_mc']]
+    assert slower <= 3, slower                                               # (two measurement runs on different boxes)
+
+
 def test_bench_byte_model_splits_into_step_kinds():
     """bench.py's algorithmic (flops, bytes, launches) of a kernel family = its alpha-step launches + its w-step launches
     (what roofline.by_mode divides the two event-time buckets by); weight-gradient families have no alpha-step part."""

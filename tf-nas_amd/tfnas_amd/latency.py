@@ -15,9 +15,11 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 
 def load_lat_lookup(which='gpu'):
     """'gpu' / 'cpu': the reference's tables (inference latency of the derived blocks on a Titan RTX / Xeon 6130);
-    'mi355x': measured by lut_builder.py on an MI355X -- NOTE it times the search net's *training-mode* forward (batch-statistic
-    BatchNorm, batch 32), so it ranks candidates by HIP training-forward time, not by deployment latency."""
-    if which in ('gpu', 'cpu', 'mi355x'):      # gpu / cpu: the reference's tables; mi355x: measured here (lut_builder.py)
+    'mi355x': INFERENCE latency of the derived blocks on an MI355X (eval-mode affine BatchNorm through tfnas_mbconv_fwd, batch 32,
+    device-timed) -- the reference's meaning, measured by lut_builder.py (mode='inference');
+    'mi355x_search': the search net's *training-mode* forward (batch-statistic BatchNorm) of rounds 2-3 -- HIP training-forward time,
+    not deployment latency."""
+    if which in ('gpu', 'cpu', 'mi355x', 'mi355x_search'):      # gpu / cpu: the reference's tables; mi355x*: measured here
         path = os.path.join(_DATA, 'latency_%s.npz' % which)
     else:
         path = which

@@ -13,12 +13,13 @@ interpolated linearly in between, the scheme the reference sketches in its comme
 (:494-518).  Widths <= in_channels are not reachable by the search (an MBConv has an expand convolution only when
 mid > in, layers.py:462; elasticity scaling never goes below max/2 = 2*in) and get the smallest measured value.
 
-WHAT THE TABLE MEANS (differs from the reference's): the timed launch sequence is the SEARCH net's sampled-mode forward --
-train-mode batch-statistic BatchNorm without affine parameters at batch 32 -- not the inference forward of the derived block
-(eval-mode affine BatchNorm folded into the convolutions) that the reference's pickles hold.  The latency term of the
-architecture step and elasticity scaling therefore steer towards "HIP training-forward time on MI355X"; relative candidate
-costs track deployment latency (same convolutions, same tensors), absolute values do not.  Use the reference's 'gpu' / 'cpu'
-tables when the target is the reference's deployment latency.
+WHAT THE TABLE MEANS.  ``mode='inference'`` (the default since round 4, ``data/latency_mi355x.npz``): the INFERENCE forward of the
+derived block -- ``tfnas_mbconv_fwd`` with eval-mode affine BatchNorm (running statistics, nothing reduced over the batch), the
+launch sequence ``model_eval.Network.eval()(x)`` runs for that block -- at batch 32; 'base' is the eval-mode stem + feature-mix
++ pool + classifier of the derived network.  That is the reference's meaning (make_lat_lut_example.py builds each block, calls
+``.eval()`` semantics through ``measure_latency_in_ms``, tools/utils.py:12-34).  ``mode='search'`` keeps rounds 2-3's table
+(``data/latency_mi355x_search.npz``): the SEARCH net's sampled-mode forward with train-mode batch-statistic BatchNorm -- "HIP
+training-forward time", useful only for predicting the search's own step time.
 """
 import ctypes as C
 import pickle
@@ -45,8 +46,10 @@ class _BlockTimer:
             t = self.bufs[name] = torch.zeros(int(n * 1.25) + 64, device=self.dev, dtype=dtype)   # zero: `part` ticket counters
         return t
 
-    def measure(self, ic, mc, se, oc, k, stride, act, size, batch=32, warmup=3, iters=10, reps=3):
+    def measure(self, ic, mc, se, oc, k, stride, act, size, batch=32, warmup=3, iters=10, reps=3, mode='inference'):
         lib, dev = self.lib, self.dev
+        if mode not in ('inference', 'search'):
+            raise ValueError(mode)
         d = _lib.TfnasCellDesc()
         d.N, d.H, d.W, d.ic, d.oc, d.stride = batch, size, size, ic, oc, stride
         d.mode, d.act, d.G, d.need_wgrad, d.eps = _lib.MODE_CELL, _lib.ACT[act], 1, 0, BN_EPS
@@ -70,18 +73,39 @@ class _BlockTimer:
         part, out = self._buf('part', ws.part), self._buf('out', ws.out)
         stream = torch.cuda.current_stream(dev)
         sp = C.c_void_p(stream.cuda_stream)
-        args = (C.byref(d), _lib.ptr(x), None, _lib.ptr(E), _lib.ptr(D), _lib.ptr(Pr), _lib.ptr(fs), _lib.ptr(st),
-                _lib.ptr(part), _lib.ptr(out), sp)
+        if mode == 'search':
+            fn, what = lib.tfnas_mixedop_fwd, 'tfnas_mixedop_fwd'
+            args = (C.byref(d), _lib.ptr(x), None, _lib.ptr(E), _lib.ptr(D), _lib.ptr(Pr), _lib.ptr(fs), _lib.ptr(st),
+                    _lib.ptr(part), _lib.ptr(out), sp)
+        else:
+            # eval-mode affine BatchNorm at the three sites (mc, mc, oc channels): gamma ~ 1, beta ~ 0, running mean 0 / var 1
+            fn, what = lib.tfnas_mbconv_fwd, 'tfnas_mbconv_fwd'
+            nb = 2 * mc + oc
+            aff = self._buf('bn', 4 * nb + 64)
+            aff[:nb].normal_(1.0, 0.05)
+            aff[nb:2 * nb].normal_(0.0, 0.05)
+            aff[2 * nb:3 * nb].zero_()
+            aff[3 * nb:4 * nb].fill_(1.0)
+            bn = _lib.TfnasBnAffine()
+            o2 = 0
+            for site, ch in enumerate((mc, mc, oc)):
+                for fi, f in enumerate(('weight', 'bias', 'running_mean', 'running_var')):
+                    getattr(bn, f)[site] = aff.data_ptr() + 4 * (fi * nb + o2)
+                o2 += ch
+            bn.momentum, bn.eval = 0.1, 1
+            self._bn = bn                                   # (keep the struct alive while its launches are enqueued)
+            args = (C.byref(d), C.byref(bn), None, _lib.ptr(x), _lib.ptr(E), _lib.ptr(D), _lib.ptr(Pr), _lib.ptr(fs),
+                    _lib.ptr(st), _lib.ptr(part), _lib.ptr(out), sp)
         for _ in range(warmup):
-            _lib.check(lib.tfnas_mixedop_fwd(*args), 'tfnas_mixedop_fwd')
+            _lib.check(fn(*args), what)
         times = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            rcs = [lib.tfnas_mixedop_fwd(*args) for _ in range(iters)]
+            rcs = [fn(*args) for _ in range(iters)]
             e1.record(stream)
-            for rc in rcs:
-                _lib.check(rc, 'tfnas_mixedop_fwd')
+            for rc in rcs:                                  # (every return code of the timed loop is checked)
+                _lib.check(rc, what)
             e1.synchronize()
             times.append(e0.elapsed_time(e1) / iters)
         return float(np.median(times))
@@ -102,11 +126,19 @@ def lut_keys():
     return out
 
 
-def measure_base(device, batch=32, iters=10):
+def measure_base(device, batch=32, iters=10, mode='inference'):
     """'base': first_stem + second_stem + feature_mix_layer + global pool + classifier (make_lat_lut_example.py:47-70),
-    timed on the HIP stem / head entry points + the classifier GEMM."""
-    from .model_search import Network
-    net = Network(1000, geometry.initial_mc_num_dddict(), {'base': 0.0}).to(device)
+    timed on the HIP stem / head entry points + the classifier GEMM; ``inference``: the derived network's eval-mode modules
+    (affine BatchNorm, running statistics), ``search``: the search net's train-mode ones."""
+    if mode == 'inference':
+        from collections import OrderedDict as OD
+        from .model_eval import Network as Derived
+        mc = geometry.initial_mc_num_dddict()
+        arch = OD((st, OD((b, 1) for b in list(bl)[:1])) for st, bl in mc.items())
+        net = Derived(1000, arch, mc, None, 0.0, 0.0).to(device).eval()
+    else:
+        from .model_search import Network
+        net = Network(1000, geometry.initial_mc_num_dddict(), {'base': 0.0}).to(device)
     x = torch.randn(batch, 3, 224, 224, device=device)
     f = torch.randn(batch, 320, 7, 7, device=device).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
@@ -123,17 +155,18 @@ def measure_base(device, batch=32, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-def build_latency_lookup(device='cuda', step=8, batch=32, iters=10, progress=None, keys=None):
-    """Measure the table on the current GPU.  ``step``: measure every step-th width (1 = every width, ~40 k measurements)."""
+def build_latency_lookup(device='cuda', step=8, batch=32, iters=10, progress=None, keys=None, mode='inference'):
+    """Measure the table on the current GPU.  ``step``: measure every step-th width (1 = every width, ~40 k measurements);
+    ``mode``: 'inference' (the reference's meaning) or 'search' (see the module docstring)."""
     dev = torch.device(device)
     timer = _BlockTimer(dev)
     lut = OrderedDict()
-    lut['base'] = measure_base(dev, batch, iters)
+    lut['base'] = measure_base(dev, batch, iters, mode)
     for key, gm in (keys or lut_keys()):
         lo, hi = gm['ic'] + 1, gm['max_mc']
         widths = sorted(set(list(range(lo, hi + 1, step)) + [hi]))
         ms = [timer.measure(gm['ic'], w, gm['se'], gm['oc'], gm['k'], gm['stride'], gm['act'], gm['size'], batch,
-                            iters=iters) for w in widths]
+                            iters=iters, mode=mode) for w in widths]
         dense = np.interp(np.arange(1, hi + 1), widths, ms)          # (clamps to the end values outside [lo, hi])
         lut[key] = OrderedDict((w + 1, float(dense[w])) for w in range(hi))
         if progress:

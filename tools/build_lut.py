@@ -12,10 +12,11 @@ from tfnas_amd import lut_builder  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--step', type=int, default=8)
+ap.add_argument('--mode', default='inference', choices=['inference', 'search'])
 ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'latency_mi355x.npz'))
 args = ap.parse_args()
 t0 = time.time()
-lut = lut_builder.build_latency_lookup(step=args.step, progress=print)
+lut = lut_builder.build_latency_lookup(step=args.step, progress=print, mode=args.mode)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
 lut_builder.save_lat_lookup(lut, args.out)
 print('base %.4f ms, %d keys, %.0f s -> %s' % (lut['base'], len(lut) - 1, time.time() - t0, args.out))
