@@ -208,6 +208,86 @@ def _pair_with_widths(lut, mc, seed=2, T=5.0):
     return o, m.cuda()
 
 
+def _dropin_pair_grads(lut, side, module_paths=True, B=8, noise=True):
+    """The reference's bi-sampling weight step written against the drop-in model (train_search.py:370-385): two sampled forwards
+    of one batch, ONE backward of the summed loss; returns the gradients torch's clip / optimizer would read."""
+    import torch.nn.functional as F
+    from tfnas_amd import model_search as ms
+    old = (ms.SECOND_PATH_ON_SIDE_STREAM, ms.MODULE_PATHS)
+    ms.SECOND_PATH_ON_SIDE_STREAM, ms.MODULE_PATHS = side, module_paths
+    try:
+        _, m = _pair(lut)
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn(B, 3, 224, 224, generator=g).cuda()
+        y = torch.randint(0, 100, (B,), generator=g).cuda()
+        e = torch.empty(18, 8).exponential_(generator=g).cuda() if noise else None
+        rp = [int(v) for v in torch.randint(0, 7, (18,), generator=g)]
+        for p in m.arch_parameters():
+            p.requires_grad = False
+        out = []
+        for it in range(2):                                   # (second iteration: arena views / streams already set up)
+            lg, _ = m(x, True, 'gumbel', exp_noise=e)
+            ia = [c.last_idx for c in m.cells()]
+            lr_, _ = m(x, True, 'random', rand_pos=rp)
+            ib = [c.last_idx for c in m.cells()]
+            loss = F.cross_entropy(lg, y) + F.cross_entropy(lr_, y)
+            for p in m.parameters():
+                p.grad = None
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(m.weight_parameters(), 5.0)          # (reads every gradient on the caller's stream)
+            out.append((float(loss), float(gn), ia, ib,
+                        {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+        torch.cuda.synchronize()
+        return out
+    finally:
+        ms.SECOND_PATH_ON_SIDE_STREAM, ms.MODULE_PATHS = old
+
+
+def test_dropin_second_path_on_side_stream_is_bit_identical(lut):
+    """Network.forward of the module API: the 'random' forward of a bi-sampling pair runs on a second HIP stream (its backward
+    too); same kernels, same results as with both paths on the caller's stream, and as the per-cell route."""
+    a = _dropin_pair_grads(lut, True)
+    b = _dropin_pair_grads(lut, False)
+    c = _dropin_pair_grads(lut, False, module_paths=False)
+    for (la, na, ia, ib, ga), (lb, nb, ja, jb, gb), (lc, nc, ka, kb, gc) in zip(a, b, c):
+        assert ia == ja == ka and ib == jb == kb and all(u != v for u, v in zip(ia, ib))
+        assert la == lb == lc and na == nb
+        assert set(ga) == set(gb) == set(gc) and len(ga) > 100
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+            assert torch.equal(ga[k], gc[k]), k
+
+
+def test_dropin_host_side_gumbel_sampling_follows_the_log_alphas(lut):
+    """Without caller noise the drop-in forward samples 'gumbel' positions on the host from a staged copy of the log_alphas (no
+    blocking device->host copy per step).  The copy must be re-staged when the caller replaces the arch tensors the way
+    train_search.py:420-422 does (``p.data = log_softmax(...)``): with one candidate's log_alpha far above the rest every cell
+    must pick it; positions stay valid raw indices; a second model with the same torch seed draws the same architectures."""
+    import torch.nn.functional as F
+    picks = []
+    for rep in range(2):
+        _, m = _pair(lut, seed=7)
+        x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+        seq = []
+        with torch.no_grad():
+            for it in range(3):
+                m(x, True, 'gumbel')
+                seq.append([c.last_idx for c in m.cells()])
+                m.reset_switches()
+            for k, c in enumerate(m.cells()):
+                la = torch.full((8,), -20.0, device='cuda')
+                la[k % 8] = 0.0
+                c.log_alphas.data = F.log_softmax(la, dim=-1)
+            m(x, True, 'gumbel')
+            forced = [c.last_idx for c in m.cells()]
+            m.reset_switches()
+        assert forced == [k % 8 for k in range(18)]
+        assert all(0 <= i < 8 for s_ in seq for i in s_) and len({tuple(s_) for s_ in seq}) > 1
+        picks.append(seq)
+    assert picks[0] == picks[1]
+
+
+
 @pytest.mark.parametrize('widths', ['e2_e4', 'e3_e6', 'e4_e8', 'ragged_target15', 'ragged_target10', 'ragged_target18'])
 def test_width_sweep_matches_oracle(lut, widths):
     """BASELINE configs[3]: expand ratios across the reachable range + ragged widths produced by elasticity scaling

@@ -207,6 +207,7 @@ class MixedStage(nn.Module):
 # Network.forward on the path level when it can (GPU model, tfnas_amd.search.USE_PATHS): TFNAS_MODULE_PATHS=0
 # keeps the per-cell route (one autograd node per MixedOP: what the stage-by-stage tests hook into)
 MODULE_PATHS = os.environ.get('TFNAS_MODULE_PATHS', '1') != '0'
+SECOND_PATH_ON_SIDE_STREAM = True       # the 'random' forward of a bi-sampling pair on a second HIP stream (tests flip it)
 
 
 
@@ -421,19 +422,87 @@ class Network(nn.Module):
             return None                                       # soft-mode weight gradients: per-cell route
         if sampling and torch.is_grad_enabled() and any(stg.betas.requires_grad for stg in self.stages()):
             return None                                       # d betas of a sampled forward: per-cell route (SinkFn)
+        if sampling:
+            return self._sampled_on_paths(st, x, stem_out, mode, exp_noise, rand_pos, pos)
         feat = self._stem(x) if stem_out is None else stem_out
-        if not sampling:
-            W, CL = self.arch_weights(feat.size(-1), x.device, exp_noise)
-            out, stage_lat = runner.soft(feat, W, CL)
-            lat = stage_lat.sum() + self.lat_lookup['base']
-            return self.classifier(self._head(out)), lat
-        self._prepare(feat, True, mode, exp_noise, rand_pos, pos)
-        idxs = []
-        for c in cells:
-            idxs.append(int(c._pre))
-            c.last_idx, c._pre = int(c._pre), None
-        # two sampled forwards may be alive at once (the bi-sampling pair runs gumbel, random, then ONE backward)
-        out = runner.sampled(feat, idxs, name='A' if mode == 'gumbel' else 'B', expose=st)
+        W, CL = self.arch_weights(feat.size(-1), x.device, exp_noise)
+        out, stage_lat = runner.soft(feat, W, CL)
+        lat = stage_lat.sum() + self.lat_lookup['base']
+        return self.classifier(self._head(out)), lat
+
+    def _host_positions(self, st, mode, exp_noise, pos):
+        """'gumbel' positions of all cells from the host mirror of the log_alphas (search.SearchState.alpha_host: an asynchronous
+        pinned copy, re-staged only when a log_alphas tensor was replaced or modified) -- no blocking device->host copy inside a
+        weight step whose architecture parameters did not change since the last one, so the host can run ahead of the GPU.  Only
+        when the caller passes no noise of its own (the noise is then drawn on the host, seeded from torch.initial_seed()) and
+        every switch is on; otherwise the device-side sampler of ``_prepare``."""
+        from . import search
+        if mode != 'gumbel' or exp_noise is not None or pos is not None or not search.HOST_SAMPLING:
+            return pos
+        cells = self.cells()
+        if not all(all(c.switches) for c in cells):
+            return pos
+        rng = st.__dict__.get('_host_rng')
+        if rng is None:
+            import numpy as np
+            rng = st._host_rng = np.random.default_rng(torch.initial_seed() & 0xffffffff)
+        e = rng.standard_exponential((len(cells), 8), dtype='float32')
+        return search.host_gumbel_positions(st.alpha_host().numpy(), e, cells[0].T)
+
+    def _sampled_on_paths(self, st, x, feat, mode, exp_noise, rand_pos, pos):
+        runner = st.runner
+        cells = self.cells()
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        # second forward of a bi-sampling pair (train_search.py:375-379: model(x, True, 'gumbel') then model(x, True, 'random') on
+        # the SAME batch, one backward of the summed loss): enqueue it on a second HIP stream so that its kernels -- and, autograd
+        # replaying every node on its forward stream, its backward -- run beside the first path's (DESIGN.md section 4: a sampled
+        # path's launches fill a fraction of the chip).  It may start as soon as what the FIRST forward could start on is ready
+        # (the event recorded when that forward was entered), provided x and the weights are what they were then.
+        key = (x.data_ptr(), x._version, tuple(x.shape), st.weights_epoch, self.first_stem.conv.weight._version)
+        first = st.__dict__.get('_fwd_first')
+        side = None
+        if (SECOND_PATH_ON_SIDE_STREAM and mode == 'random' and torch.is_grad_enabled() and first is not None and first[0] == key and first[2] == cur
+                and feat is None):
+            side = st.side_stream(dev)
+        if mode == 'gumbel':
+            st.throttle(dev)                    # (nothing in a host-sampled step blocks the host: keep it <= 1 step ahead)
+            st.mark_step(dev)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            st._fwd_first = (key, ev, cur)
+        else:
+            st._fwd_first = None
+        if side is None:
+            feat = self._stem(x) if feat is None else feat
+            self._prepare(feat, True, mode, exp_noise, rand_pos, self._host_positions(st, mode, exp_noise, pos))
+            idxs = []
+            for c in cells:
+                idxs.append(int(c._pre))
+                c.last_idx, c._pre = int(c._pre), None
+            # two sampled forwards may be alive at once (the bi-sampling pair runs gumbel, random, then ONE backward)
+            out = runner.sampled(feat, idxs, name='A' if mode == 'gumbel' else 'B', expose=st)
+            return self.classifier(self._head(out)), 0.0
+        side.wait_event(first[1])
+        x.record_stream(side)
+        if not st.__dict__.get('_warned_off'):
+            # the stems' AccumulateGrad nodes now receive one of their two gradients from the side stream -- intended (the engine
+            # synchronises them); torch >= 2.9 warns about exactly this on every backward
+            off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if off is not None:
+                off(False)
+            st._warned_off = True
+        with torch.cuda.stream(side):
+            feat = self._stem(x)
+            self._prepare(feat, True, mode, exp_noise, rand_pos, pos)
+            idxs = []
+            for c in cells:
+                idxs.append(int(c._pre))
+                c.last_idx, c._pre = int(c._pre), None
+            out = runner.sampled(feat, idxs, name='B', expose=st, main_stream=cur)
+        cur.wait_stream(side)
+        out.record_stream(cur)
+        # (both heads on the caller's stream: the shared head / classifier parameters accumulate their two gradients there)
         return self.classifier(self._head(out)), 0.0
 
     def forward(self, x, sampling, mode='max', exp_noise=None, rand_pos=None, stem_out=None, pos=None):

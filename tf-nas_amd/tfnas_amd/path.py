@@ -295,12 +295,14 @@ class PathRunner:
     def _wants_wgrad(self, idxs):
         return torch.is_grad_enabled() and self.cells[0].m_ops[idxs[0]].point_linear.conv.weight.requires_grad
 
-    def sampled(self, x0, idxs, name='A', expose=None):
+    def sampled(self, x0, idxs, name='A', expose=None, main_stream=None):
         """One sampled path (train_wo_arch / validate / a single bi-sampling path).  ``expose``: a SearchState -- the backward
         then points ``.grad`` of the sampled candidates' parameters at the arena ranges it wrote (module-API callers that
-        run torch's clip_grad_norm_ / optimizer.step() on ``.grad``)."""
+        run torch's clip_grad_norm_ / optimizer.step() on ``.grad``).  ``main_stream``: the caller's stream when this path is
+        enqueued on ANOTHER (side) stream -- the backward then makes ``main_stream`` wait for the weight gradients it wrote
+        (they bypass autograd's AccumulateGrad and its stream bookkeeping) once the whole backward pass has been enqueued."""
         idxs = tuple(int(i) for i in idxs)
-        return OnePathFn.apply(self, x0, idxs, name, self._wants_wgrad(idxs), expose)
+        return OnePathFn.apply(self, x0, idxs, name, self._wants_wgrad(idxs), expose, main_stream)
 
     def bisampled(self, x0, idx_a, idx_b, side_stream):
         """Both bi-sampling paths of a weight step, interleaved on the current stream and ``side_stream``."""
@@ -365,11 +367,11 @@ class OnePathFn(torch.autograd.Function):
     """One sampled path; weight gradients go straight into the WeightArena (not through autograd)."""
 
     @staticmethod
-    def forward(ctx, runner, x0, idxs, name, need_w, expose=None):   # (grad mode is off inside forward: need_w comes from outside)
+    def forward(ctx, runner, x0, idxs, name, need_w, expose=None, main_stream=None):   # (grad mode is off inside forward: need_w comes from outside)
         _require_cuda(x0, 'path input')
         x0h = _nhwc(x0)
         dev = x0h.device
-        ctx.expose, ctx.idxs, ctx.need_w, ctx.name = expose, idxs, need_w, name
+        ctx.expose, ctx.idxs, ctx.need_w, ctx.name, ctx.main_stream = expose, idxs, need_w, name, main_stream
         s = runner._plan(name, idxs, x0h, need_w, ctx.needs_input_grad[1], False)
         out = _out_tensor(s, x0h.shape[0], dev)
         cur = torch.cuda.current_stream(dev)
@@ -395,7 +397,15 @@ class OnePathFn(torch.autograd.Function):
             runner._bwd(*args)
         if ctx.expose is not None and ctx.need_w:
             ctx.expose.expose_weight_grads([ctx.idxs], track=False)
-        return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None, None
+        main = ctx.main_stream
+        if main is not None and main != cur and ctx.need_w:
+            # this path ran on a side stream: whatever the caller enqueues on its own stream after backward() -- clip_grad_norm_,
+            # optimizer.step() -- reads the arena ranges written here.  Not a wait issued now (the other path's backward is
+            # enqueued on `main` after this one and must not queue up behind it) but when the engine has finished the pass.
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_event(ev))
+        return None, None if dx0 is None else dx0.permute(0, 3, 1, 2), None, None, None, None, None
 
 
 class BiPathFn(torch.autograd.Function):

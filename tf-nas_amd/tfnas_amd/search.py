@@ -49,6 +49,7 @@ class SearchState:
         self.arch = model.arch_parameters()
         self._mode = None
         self._side_stream = None
+        self.weights_epoch = 0             # bumped by the fused optimizer steps (they write through raw pointers: no ._version)
         self._alpha_host = None            # (key, pinned [ncell, 8] copy of the log_alphas, copy-done event)
         self._step_done = []               # completion events of the most recent steps (bounds host run-ahead)
         self._pin = self._pin_ev = None
@@ -201,6 +202,7 @@ class SearchState:
         import ctypes as C
         from . import _lib
         a = self.arena
+        self.weights_epoch += 1
         self._bind_momentum(opt_w)
         hp = opt_w.param_groups[0]
         dev = a.device
