@@ -82,6 +82,10 @@ def family_algorithmic(fam, B, mode=None):
             # E-free mode (functions.py policy): stride-2 cells with ic <= 24 in the alpha-step never form E; the
             # depthwise kernels recompute it from x (2*P*ic*M extra flops) and BN1's statistics are two passes over x
             efree = launches == 1 and s == 2 and ic <= 24
+            # BN2-backward tables in the epilogue of k_project_dgrad (capi.hip): one-candidate launches and images <= 28 x 28
+            HWo = Po // N
+            folded = HWo >= 43 and (launches != 1 or HWo <= 784)
+            rec_bytes = 4.0 * (Po / 128.0) * (1.0 + 128.0 / HWo) * 3.5 * M    # ~(5 + 2) / 2 sums per (row tile, image, channel)
             if fam == 'k_expand_fwd' and efree:
                 f, b, kernels = 2.0 * P * ic * ic, 4.0 * (2 * P * ic), 2
             elif fam == 'k_dw_fwd' and efree:
@@ -94,6 +98,8 @@ def family_algorithmic(fam, B, mode=None):
                 f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + G * Po * oc + M * oc)
             elif fam == 'k_project_dgrad':
                 f, b = 2.0 * Po * M * oc, 4.0 * (2 * G * Po * oc + Po * M + M * oc)
+                if folded:                                     # FOLD epilogue (capi.hip policy): + one read of D + the records
+                    b += 4.0 * Po * M + rec_bytes
             elif fam == 'k_expand_dgrad':
                 f, b = 2.0 * P * M * ic, 4.0 * (2 * P * M + P * ic + M * ic)
             elif fam == 'k_dw_fwd':
@@ -104,6 +110,8 @@ def family_algorithmic(fam, B, mode=None):
                 f, b = 2.0 * P * M * kk / (s * s), 4.0 * (2 * Po * M + 2 * P * M)
             elif fam == 'k_se_pool<bwd>':                      # k_bn2_pool: ONE pass over (dZ, D); k_bn2_finish is tiny
                 f, b = 8.0 * Po * M, 4.0 * (2 * Po * M)
+                if folded:                                     # k_bn2_gather: only the records of the dgrad epilogue
+                    f, b = 0.0, rec_bytes
             elif fam in ('k_project_wgrad', 'k_expand_wgrad', 'k_dw_wgrad'):
                 if launches == 1:
                     continue                                   # no weight grads in the alpha-step
@@ -299,6 +307,34 @@ def retrain_leg(dev, batch=256, steps=10, warmup=3):
                params_M=round(sum(p.numel() for p in model.parameters()) / 1e6, 3))
     if not deterministic:
         raise RuntimeError('bench: the retrain step is not bit-deterministic')
+    # the reference's retrain script also exists with mixed precision (train_eval_amp.py:176-180,331-333: apex O1).  The same
+    # step with the 1x1 GEMMs on the bf16 MFMA pipe (tfnas_set_gemm_mode(TFNAS_GEMM_BF16): bf16 operands, fp32 accumulation, fp32
+    # storage / statistics / master weights) -- a SECONDARY, reduced-precision figure with its loss beside the fp32 one's
+    from tfnas_amd import _lib
+    lib = _lib.lib()
+    prev = lib.tfnas_gemm_mode()
+    try:
+        res = {}
+        for tag, mode in (('fp32', prev), ('bf16', 1)):
+            _lib.check(lib.tfnas_set_gemm_mode(mode), 'tfnas_set_gemm_mode')
+            torch.manual_seed(0)
+            m2 = me.Network(1000, arch, mc, lut, 0.0, 0.0).to(dev)
+            o2 = torch.optim.SGD(m2.parameters(), 0.05, momentum=0.9, weight_decay=4e-5)
+            for _ in range(warmup):
+                me.train_step(m2, x, y, crit, o2, 5.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss2, _ = me.train_step(m2, x, y, crit, o2, 5.0)
+            torch.cuda.synchronize()
+            res[tag] = (batch * steps / (time.perf_counter() - t0), float(loss2))
+            _require_finite(m2, 'the retrain leg (%s GEMMs)' % tag)
+            del m2, o2
+        out['bf16_gemm'] = dict(images_per_s=round(res['bf16'][0], 1), vs_fp32=round(res['bf16'][0] / res['fp32'][0], 3),
+                                **{'loss_after_%d_steps' % (warmup + steps): round(res['bf16'][1], 4)}, fp32_loss=round(res['fp32'][1], 4),
+                                note='bf16 MFMA operands in the 1x1 GEMMs only; tensors stay fp32 in HBM (DESIGN.md section 4a)')
+    finally:
+        lib.tfnas_set_gemm_mode(prev)
     del model, opt
     torch.cuda.empty_cache()
     return out

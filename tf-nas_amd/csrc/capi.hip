@@ -313,6 +313,13 @@ static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     return 0;
 }
 
+// TFNAS_FOLD = 1 (default) | 0: BN2-backward tables in the epilogue of k_project_dgrad / in their own pass (k_bn2_pool); both
+// are compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
+static const bool g_project_fold = [] {
+    const char* e = getenv("TFNAS_FOLD");
+    return !(e && e[0] == '0');
+}();
+
 int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdBufs& b0, hipStream_t s, const CellSide* so) {
     const TfnasBnAffine* bn = b0.bn;
     TfnasCellDesc dc = d0;
@@ -359,10 +366,21 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     // weight gradients: on the side stream, scratch = part_w
     if (d.need_wgrad)
         TRY(launch_project_wgrad(d, b.dout, b.Pr, b.D, gate, stats2, stats3, red3, b.wmix, part_w, fork_to(so, 0, s)));
-    TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s)); // dZ = dP W_proj
     const bool fused2 = bn2_fused_fits(d);
-    if (fused2) TRY(launch_bn2_pool(d, b.dZ, b.D, stats2, dgate, part, s));       // d gate + per-image BN2-backward tables
-    else TRY(launch_se_bwd_reduce(d, b.dZ, b.D, stats2, dgate, s));             // SE groups: d gate
+    // dZ = dP W_proj; where the geometry allows, the per-image BN2-backward tables are accumulated in its epilogue (records in
+    // dEh, which nothing reads or writes before the SE backward below) and gathered -- no second pass over dZ
+    // (policy, measured per cell at B = 128: the epilogue's column-wise D loads cost more than k_bn2_pool's streaming pass on the
+    //  write-bound all-candidate launches of the 112 x 112 / 56 x 56 cells -- cell 1: 0.99 -> 1.04 ms -- and less everywhere else:
+    //  cell 10 sampled 0.126 -> 0.103 ms, cell 15 all candidates 0.286 -> 0.252 ms)
+    const bool fold = fused2 && g_project_fold && project_fold_ok(d, (size_t)ws.dEh) && (d.G == 1 || d.Ho * d.Wo <= 784);
+    if (fold) {
+        TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s, b.D, stats2, b.dEh));
+        TRY(launch_bn2_gather(d, b.dEh, dgate, part, s));
+    } else {
+        TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s));
+        if (fused2) TRY(launch_bn2_pool(d, b.dZ, b.D, stats2, dgate, part, s));   // d gate + per-image BN2-backward tables
+        else TRY(launch_se_bwd_reduce(d, b.dZ, b.D, stats2, dgate, s));         // SE groups: d gate
+    }
     // (K-split partials of the SE backward go through dEh, which is only written by the depthwise dgrad further down)
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)ws.dEh, s));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums

@@ -346,8 +346,13 @@ __device__ __forceinline__ void flush_colstats(float (&s)[NT], float (&q)[NT], f
 // Emit the 128 x BN accumulator tile as 16-byte pieces of rows: emit(local_row, local_col (multiple of 4), f32x4).
 // The MFMA C layout gives a lane 4 rows x 1 column per 16x16 tile, so a direct store writes 64-byte row segments;
 // staging 16 rows per wave through LDS turns that into whole contiguous row pieces (256 B per row at BN = 64).
-template <int NT, class FEmit>
-__device__ __forceinline__ void emit_tile_rows(const f32x4 (&acc)[2][NT], float* lds, FEmit emit) {
+struct SlabNone {
+    __device__ __forceinline__ void operator()(int, const float*) const {}
+};
+// `slab(i, st)`: optional hook called by every wave after the stores of its slab i, while the slab (16 rows x BN, leading
+// dimension BN + 4) is still in LDS at `st`
+template <int NT, class FEmit, class FSlab = SlabNone>
+__device__ __forceinline__ void emit_tile_rows(const f32x4 (&acc)[2][NT], float* lds, FEmit emit, FSlab slab = FSlab()) {
     using T = GT<NT>;
     constexpr int LDC = T::BN + 4, Q = T::BN / 4;
     static_assert(4 * 16 * LDC <= T::LDS_FLOATS, "C staging does not fit the GEMM LDS buffer");
@@ -369,6 +374,7 @@ __device__ __forceinline__ void emit_tile_rows(const f32x4 (&acc)[2][NT], float*
                 emit(w * 32 + 16 * i + row, 4 * c4, ld4(st + row * LDC + 4 * c4));
             }
         }
+        slab(i, st);
     }
     __syncthreads();
 }

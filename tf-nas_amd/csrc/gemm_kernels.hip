@@ -343,14 +343,68 @@ __device__ __forceinline__ f32x4 bn3_fold_dp(const f32x4* tab, int o, f32x4 dout
     return r;
 }
 
+// ---------------------------------------------------------------------------- BN2-backward sums in the dgrad epilogue
+// FOLD variant of k_project_dgrad (round 4): the per-image tables that k_bn2_pool computed in its own pass
+// over (dZ, D) -- A1 = sum dZ act'(dhat), B1 = sum dZ act'(dhat) dhat, dgate = sum dZ act(dhat), A2 = sum act'(dhat),
+// B2 = sum act'(dhat) dhat over the pixels of one image (pointwise_kernels.hip) -- are accumulated while the dZ tile is still in
+// LDS: dZ is then written once and never read back for them (the D read stays).  A lane owns one or two COLUMNS of the tile and
+// walks the 16 rows of its wave's slab: column-contiguous dword loads of D (256 B per row and wave), no cross-lane reduction.
+// A wave's 32 rows touch at most two images (HW >= 43), a 128-row tile at most four: one record per (row tile, image slot)
+//   rec[((rt * 4 + slot) * 5 + q) * M + channel],  slot = image - image_of(rt * 128),  q = A1 | B1 | dgate | A2 | B2
+// each written by exactly one workgroup (no atomics, fixed summation order); k_bn2_gather sums an image's records.
+template <int NT, int ACT>
+__device__ __forceinline__ void fold_slab(const float* st, int LDC, const float* __restrict__ Dcol, int M, int p0, int Po, int bnd,
+                                          const float2 (&c2)[(16 * NT + 63) / 64], const bool (&cok)[(16 * NT + 63) / 64],
+                                          bool has_se, float (&sum)[2][FOLD_Q][(16 * NT + 63) / 64]) {
+    constexpr int NC = (16 * NT + 63) / 64;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (!cok[c]) continue;
+        const int col = lane + 64 * c;
+        float dv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv[r] = __builtin_nontemporal_load(Dcol + (size_t)min(p0 + r, Po - 1) * M + col);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + r;
+            if (p >= Po) break;                                     // (wave-uniform)
+            const float z = st[r * LDC + col];
+            const float dh = (dv[r] - c2[c].x) * c2[c].y;
+            const float ad = act_d<ACT>(dh), zd = z * ad;
+            const float v2 = has_se ? z * act_f<ACT>(dh) : 0.f;
+            if (p >= bnd) {                                         // (wave-uniform: the row belongs to the wave's second image)
+                sum[1][0][c] += zd;
+                sum[1][1][c] += zd * dh;
+                if (has_se) {
+                    sum[1][2][c] += v2;
+                    sum[1][3][c] += ad;
+                    sum[1][4][c] += ad * dh;
+                }
+            } else {
+                sum[0][0][c] += zd;
+                sum[0][1][c] += zd * dh;
+                if (has_se) {
+                    sum[0][2][c] += v2;
+                    sum[0][3][c] += ad;
+                    sum[0][4][c] += ad * dh;
+                }
+            }
+        }
+    }
+}
+
 // ============================================================================ project dgrad
 // dZ[p][off_g + c] = sum_o dP_g[p][o] * w_proj_g[o][c]
-template <int NT, int MM>
+template <int NT, int MM, bool FOLD = false>
 __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_dgrad(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr,
                                                        const double* __restrict__ stats3,
                                                        const double* __restrict__ red3,
-                                                       const float* __restrict__ wmix, float* __restrict__ dZ) {
+                                                       const float* __restrict__ wmix, float* __restrict__ dZ,
+                                                       const float* __restrict__ D = nullptr,
+                                                       const double* __restrict__ stats2 = nullptr,
+                                                       float* __restrict__ rec = nullptr) {
     using T = GT<NT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int ty = blockIdx.y, g = 0;
@@ -370,6 +424,21 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_dgrad(TfnasCel
 
     f32x4* tab = reinterpret_cast<f32x4*>(lds + T::LDS_FLOATS);
     bn3_fold_fill(tab, ocp, d, g, stats3, red3, wmix);
+    // FOLD: BN2 constants of this lane's one or two columns of the (fixed) column tile
+    constexpr int NC = (T::BN + 63) / 64;
+    float2 c2f[NC];
+    bool cokf[NC];
+    const int HW = d.Ho * d.Wo;
+    const bool has_se = d.g[g].se > 0;
+    if (FOLD) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = (tid & 63) + 64 * c;
+            cokf[c] = col < T::BN && n0 + col < mcp;
+            c2f[c] = (cokf[c] && n0 + col < mc) ? bn_consts(stats2 + 2 * (size_t)(off + n0 + col), 1.0 / (double)Po, d.eps)
+                                               : make_float2(0.f, 0.f);
+        }
+    }
     __syncthreads();
 
     for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
@@ -408,18 +477,76 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_project_dgrad(TfnasCel
         };
         PreNone pre;
         gemm_adirect<NT, false, MM>(pre, la, xa, lb, xb, nchunks, acc, lds);
-        emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
-            const int p = rt * 128 + lrow;
-            if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
-        });
+        if (!FOLD) {
+            emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
+                const int p = rt * 128 + lrow;
+                if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
+            });
+        } else {
+            constexpr int LDC = T::BN + 4;
+            const int w = tid >> 6, lane = tid & 63;
+            const int pw0 = rt * 128 + w * 32;
+            const int imgA = min(pw0, Po - 1) / HW, bnd = (imgA + 1) * HW;
+            float sum[2][FOLD_Q][NC];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < FOLD_Q; ++q)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) sum[a][q][c] = 0.f;
+            const float* Dcol = D + off + n0;
+            emit_tile_rows<NT>(acc, lds,
+                               [&](int lrow, int lc, f32x4 v) {
+                                   const int p = rt * 128 + lrow;
+                                   if (p < Po && n0 + lc < mcp) stS4_nt(dZ, (size_t)p * M + off + n0 + lc, v, d.stor);
+                               },
+                               [&](int i, const float* st) {        // the wave's slab i (16 rows x BN) is still in LDS
+                                   if (d.act == TFNAS_ACT_RELU)
+                                       fold_slab<NT, TFNAS_ACT_RELU>(st, LDC, Dcol, M, pw0 + 16 * i, Po, bnd, c2f, cokf, has_se, sum);
+                                   else
+                                       fold_slab<NT, TFNAS_ACT_SWISH>(st, LDC, Dcol, M, pw0 + 16 * i, Po, bnd, c2f, cokf, has_se, sum);
+                               });
+            // waves -> image slots of the tile, in wave order (emit_tile_rows ended with a barrier: the GEMM LDS is free)
+            static_assert(4 * 2 * FOLD_Q * T::BN + 4 <= T::LDS_FLOATS, "fold staging does not fit the GEMM LDS buffer");
+            float* comb = lds;                                      // [4 waves][2 segments][5][BN]
+            int* meta = reinterpret_cast<int*>(lds + 4 * 2 * FOLD_Q * T::BN);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < FOLD_Q; ++q)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (lane + 64 * c < T::BN) comb[((w * 2 + a) * FOLD_Q + q) * T::BN + lane + 64 * c] = sum[a][q][c];
+            if (lane == 0) meta[w] = imgA;
+            __syncthreads();
+            const int img0 = min(rt * 128, Po - 1) / HW, imgL = min(rt * 128 + 127, Po - 1) / HW;
+            const int nq = has_se ? FOLD_Q : 2;
+            for (int o = tid; o < FOLD_SLOTS * FOLD_Q * T::BN; o += 256) {
+                const int sl = o / (FOLD_Q * T::BN), q = (o / T::BN) % FOLD_Q, col = o % T::BN;
+                if (img0 + sl > imgL || q >= nq || n0 + col >= mcp) continue;
+                float t = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if (meta[ww] + a - img0 == sl) t += comb[((ww * 2 + a) * FOLD_Q + q) * T::BN + col];
+                rec[(((size_t)rt * FOLD_SLOTS + sl) * FOLD_Q + q) * M + off + n0 + col] = t;
+            }
+            __syncthreads();
+        }
     }
 }
+
+// Weight-gradient GEMMs: workgroups per CU the register budget must allow (tools/wg_timeline.py, round 4: the 7-tile variants
+// took 260 / 248 registers -> ONE workgroup per CU, a 330-workgroup launch ran as two rounds of 65 us with every SIMD waiting on
+// one wave's loads).  The split count below is sized to exactly these resident slots.
+constexpr int wgrad_lb(int nt) { return nt >= 5 ? 2 : (nt >= 3 ? 3 : 4); }
 
 // ============================================================================ project wgrad (TN, split-K)
 // part[split][poff_g + o*mc + c] = sum_{p in split} dP_g[p][o] * z_g[p][c]   (k_reduce_rows sums the splits)
 // tile: M side = mid channels c (128), N side = output channels o (16*NT)
 template <int NT, int ACT>
-__global__ __launch_bounds__(256) void k_project_wgrad(TfnasCellDesc d, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, wgrad_lb(NT)) void k_project_wgrad(TfnasCellDesc d, const float* __restrict__ dout,
                                                        const float* __restrict__ Pr, const float* __restrict__ D,
                                                        const float* __restrict__ gate,
                                                        const double* __restrict__ stats2,
@@ -778,7 +905,7 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
 // ============================================================================ expand wgrad (TN, split-K)
 // part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]   (k_reduce_rows sums the splits)
 template <int NT, bool STEM>
-__global__ __launch_bounds__(256) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
+__global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ E, const float* __restrict__ cb1,
                                                       const float* __restrict__ x, int rows_per_split,
                                                       float* __restrict__ part, size_t out_size) {
@@ -1061,13 +1188,29 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
     return launch_reduce_rows(part, grid.x, ncols2, (size_t)ncols2, stats3, nullptr, s);
 }
 
+#define TFNAS_FOLD_LAUNCH(NT_)                                                                                           \
+    hipLaunchKernelGGL((k_project_dgrad<NT_, MM, true>), grid, dim3(256),                                               \
+                       (GT<NT_>::LDS_FLOATS + 4 * ((d.oc + 15) & ~15)) * sizeof(float), s, d, dout, Pr, stats3, red3, wmix, dZ, \
+                       D, stats2, rec)
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         const double* red3, const float* wmix, float* dZ, hipStream_t s) {
+                         const double* red3, const float* wmix, float* dZ, hipStream_t s, const float* D,
+                         const double* stats2, float* rec) {
     ProfScope _prof(TK_PROJECT_DGRAD, s);
     const int nt = pick_nt_groups(d), mm = gemm_mode_dgrad(d);
     int tiles = 0;
     for (int g = 0; g < d.G; ++g) tiles += cdiv(d.g[g].mcp, 16 * nt);
     dim3 grid(row_blocks(d.N * d.Ho * d.Wo, tiles, 1u << 30, gemm_slots(nt, mm)), tiles);
+    if (rec) {
+        if (!D || !stats2) return TFNAS_ENULL;
+        DISPATCH_MM_(mm, {
+            switch (nt) {                                   // (pick_nt_groups only returns 4, 5 or 7)
+                case 5: TFNAS_FOLD_LAUNCH(5); break;
+                case 7: TFNAS_FOLD_LAUNCH(7); break;
+                default: TFNAS_FOLD_LAUNCH(4); break;
+            }
+        })
+        return (int)hipGetLastError();
+    }
     DISPATCH_MM_(mm, DISPATCH_NT(nt, {
         const size_t shm = (GT<NT>::LDS_FLOATS + 4 * ((d.oc + 15) & ~15)) * sizeof(float);
         hipLaunchKernelGGL((k_project_dgrad<NT, MM>), grid, dim3(256), shm, s, d, dout, Pr, stats3, red3, wmix, dZ);
@@ -1075,11 +1218,12 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
     return (int)hipGetLastError();
 }
 
-static int pick_rows_per_split(int rows, int out_tiles, size_t out_size) {
-    // aim for ~1024 workgroups, at least 256 rows (16 K-chunks) per split, partial tiles must fit the scratch
-    // (swept 512 ... 2048 workgroups x 128 ... 512 rows: flat within 2 %, worse below)
-    const int target = 1024, min_rows = 256;
-    int splits = cdiv(target, out_tiles > 0 ? out_tiles : 1);
+static int pick_rows_per_split(int rows, int out_tiles, size_t out_size, int nt) {
+    // ONE resident round: as many workgroups as the chip holds of this variant (256 CUs x wgrad_lb), never a second, mostly
+    // empty round (cell 10: 55 splits x 6 tiles = 330 workgroups on 256 slots ran 2 x 65 us); at least 128 rows (8 K-chunks)
+    // per split; partial tiles must fit the scratch
+    const int target = 256 * wgrad_lb(nt), min_rows = 128;
+    int splits = target / (out_tiles > 0 ? out_tiles : 1);
     const size_t cap = TFNAS_PART_FLOATS / (out_size > 0 ? out_size : 1);
     if ((size_t)splits > cap) splits = (int)cap;
     if (splits < 1) splits = 1;
@@ -1099,7 +1243,7 @@ int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float*
     const int mtiles = cdiv(mcp_max, 128), ntiles = cdiv(d.oc, 16 * nt);
     size_t out_size = 0;
     for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.oc;
-    const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G, out_size);
+    const int rps = pick_rows_per_split(Po, mtiles * ntiles * d.G, out_size, nt);
     dim3 grid(cdiv(Po, rps), mtiles, ntiles * d.G);
     DISPATCH_NT(nt, DISPATCH_ACT(d.act, {
         size_t shm = (GT<NT>::LDS_FLOATS + 5 * ((d.oc + 15) & ~15)) * sizeof(float);
@@ -1192,7 +1336,7 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
     const int ntiles = cdiv(d.ic, 16 * nt);
     size_t out_size = 0;
     for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.ic;
-    const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size);
+    const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size, nt);
     dim3 grid(cdiv(P, rps), mtiles, ntiles);
     DISPATCH_NT(nt, {
         if (d.mode == TFNAS_MODE_STEM)

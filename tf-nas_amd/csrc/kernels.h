@@ -24,8 +24,17 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
                       hipStream_t s);
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
                        float* Pr, double* stats3, float* part, hipStream_t s);
+// D / stats2 / rec non-NULL: FOLD variant -- the per-image BN2-backward tables are accumulated in the epilogue into `rec`
+// (project_fold_ok(d, floats of rec) must hold); launch_bn2_gather then replaces launch_bn2_pool
 int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3,
-                         const double* red3, const float* wmix, float* dZ, hipStream_t s);
+                         const double* red3, const float* wmix, float* dZ, hipStream_t s, const float* D = nullptr,
+                         const double* stats2 = nullptr, float* rec = nullptr);
+constexpr int FOLD_SLOTS = 4, FOLD_Q = 5;       // records of the FOLD epilogue: rec[((row_tile * 4 + slot) * 5 + q) * M + channel]
+static inline bool project_fold_ok(const TfnasCellDesc& d, size_t scratch_floats) {
+    const int HW = d.Ho * d.Wo;
+    const size_t nrt = ((size_t)d.N * HW + 127) / 128;
+    return HW >= 43 && nrt * FOLD_SLOTS * FOLD_Q * (size_t)d.M <= scratch_floats;
+}
 int launch_project_wgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const float* D,
                          const float* gate, const double* stats2, const double* stats3, const double* red3,
                          const float* wmix, float* part, hipStream_t s);
@@ -74,6 +83,7 @@ int launch_se_wgrad(const TfnasCellDesc& d, const float* dgate, const float* gat
 bool bn2_fused_fits(const TfnasCellDesc& d);
 int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, float* dgate,
                     float* pp, hipStream_t s);
+int launch_bn2_gather(const TfnasCellDesc& d, const float* rec, float* dgate, float* pp, hipStream_t s);
 int launch_bn2_finish(const TfnasCellDesc& d, const float* pp, const float* gate, const float* dpooled, double* red2,
                       hipStream_t s);
 int launch_bn2_bwd(const TfnasCellDesc& d, const float* dZ, const float* D, const double* stats2, const float* gate,

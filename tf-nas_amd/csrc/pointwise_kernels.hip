@@ -278,6 +278,49 @@ __global__ __launch_bounds__(256) void k_bn2_pool(TfnasCellDesc d, const float* 
     }
 }
 
+// Per-image tables from the records the FOLD epilogue of k_project_dgrad wrote (gemm_kernels.hip): image n covers the row tiles
+// n*HW/128 .. ((n+1)*HW-1)/128, its slot in tile t is n - (first image of t); summed in tile order, in double.  Writes exactly what
+// k_bn2_pool writes: pp = A1 | B1 | A2 | B2 [N][M] and dgate [N][M] (the last three for SE groups only).
+__global__ __launch_bounds__(256) void k_bn2_gather(TfnasCellDesc d, const float* __restrict__ rec, float* __restrict__ dgate,
+                                                    float* __restrict__ pp) {
+    __shared__ double sh[4][FOLD_Q][64];
+    int g, c0;
+    if (!chunk_locate(d, blockIdx.y, 64, false, g, c0)) return;
+    const int mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool has_se = d.g[g].se > 0;
+    const int HW = d.Ho * d.Wo, M = d.M, n = blockIdx.x, Po = d.N * HW;
+    const int tid = threadIdx.x, cl = tid & 63, part = tid >> 6;
+    const bool active = c0 + cl < mcp;
+    const int t0 = (n * HW) >> 7, t1 = ((n + 1) * HW - 1) >> 7;
+    const int nq = has_se ? FOLD_Q : 2;
+    double acc[FOLD_Q] = {0, 0, 0, 0, 0};
+    if (active) {
+        for (int t = t0 + part; t <= t1; t += 4) {
+            const int slot = n - min(t * 128, Po - 1) / HW;
+            const float* r = rec + (((size_t)t * FOLD_SLOTS + slot) * FOLD_Q) * M + off + c0 + cl;
+#pragma unroll
+            for (int q = 0; q < FOLD_Q; ++q)
+                if (q < nq) acc[q] += (double)r[(size_t)q * M];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < FOLD_Q; ++q) sh[part][q][cl] = acc[q];
+    __syncthreads();
+    if (part == 0 && active) {
+        const size_t NM = (size_t)d.N * M, o = (size_t)n * M + off + c0 + cl;
+        double v[FOLD_Q];
+#pragma unroll
+        for (int q = 0; q < FOLD_Q; ++q) v[q] = ((sh[0][q][cl] + sh[1][q][cl]) + sh[2][q][cl]) + sh[3][q][cl];
+        pp[o] = (float)v[0];
+        pp[NM + o] = (float)v[1];
+        if (has_se) {
+            dgate[o] = (float)v[2];
+            pp[2 * NM + o] = (float)v[3];
+            pp[3 * NM + o] = (float)v[4];
+        }
+    }
+}
+
 // red2[c] = (sum_n gate*A1 + dpooled/HW*A2, sum_n gate*B1 + dpooled/HW*B2) in double (non-SE groups: sum_n A1, sum_n B1)
 __global__ __launch_bounds__(256) void k_bn2_finish(TfnasCellDesc d, const float* __restrict__ pp,
                                                     const float* __restrict__ gate, const float* __restrict__ dpooled,
@@ -772,6 +815,12 @@ int launch_bn2_pool(const TfnasCellDesc& d, const float* dZ, const float* D, con
     const int CH = (d.N * chunk_count(d, 64, false) < 1024 && d.Ho * d.Wo >= 196) ? 32 : 64;
     dim3 grid(d.N, chunk_count(d, CH, false));
     ACT_DISPATCH(d.act, { hipLaunchKernelGGL((k_bn2_pool<ACT>), grid, dim3(256), 0, s, d, dZ, D, stats2, dgate, pp, CH); })
+    return (int)hipGetLastError();
+}
+
+int launch_bn2_gather(const TfnasCellDesc& d, const float* rec, float* dgate, float* pp, hipStream_t s) {
+    ProfScope _prof(TK_SE_BWD_REDUCE, s);
+    hipLaunchKernelGGL(k_bn2_gather, dim3(d.N, chunk_count(d, 64, false)), dim3(256), 0, s, d, rec, dgate, pp);
     return (int)hipGetLastError();
 }
 

@@ -9,11 +9,26 @@ enum TfnasKernelId {
     TK_BN2_BWD, TK_DW_BWD_DATA, TK_DW_WGRAD, TK_EXPAND_DGRAD, TK_EXPAND_WGRAD, TK_SMALL, TK_REDUCE_ROWS, TK_COUNT
 };
 
+// Ablation builds (make EXTRA=-DTFNAS_ABLATE, tools/ablate.sh; NOT the product library): every kernel launch issued inside a
+// ProfScope whose family bit is set in the environment variable TFNAS_ABLATE_MASK is dropped -- "what does the step cost without
+// this family" (its consumers then read stale data: timing only).
+#ifdef TFNAS_ABLATE
+extern thread_local int g_tfnas_skip;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                   \
+    do {                                                                      \
+        if (!g_tfnas_skip) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); \
+    } while (0)
+#endif
+
 struct ProfScope {
     int id;
     hipStream_t s;
     hipEvent_t e0;
     bool on, soft;
+#ifdef TFNAS_ABLATE
+    int prev_skip;
+#endif
     // soft: the launch covers all candidates of a cell (alpha-step); reported separately by tfnas_prof_last_split
     ProfScope(int id, hipStream_t s, bool soft = false);
     void stop();          // record the end event now (idempotent); the destructor calls it

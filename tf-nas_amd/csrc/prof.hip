@@ -16,12 +16,28 @@ static const char* kNames[TK_COUNT] = {
     "k_bn2_bwd", "k_dw_bwd_data", "k_dw_wgrad", "k_expand_dgrad", "k_expand_wgrad", "small(arch/sink/consts)",
     "k_reduce_rows"};
 
+#ifdef TFNAS_ABLATE
+#include <cstdlib>
+thread_local int g_tfnas_skip = 0;
+static unsigned ablate_mask() {
+    static const unsigned m = getenv("TFNAS_ABLATE_MASK") ? (unsigned)strtoul(getenv("TFNAS_ABLATE_MASK"), nullptr, 0) : 0u;
+    return m;
+}
+#endif
+
 ProfScope::ProfScope(int id_, hipStream_t s_, bool soft_) : id(id_), s(s_), e0(nullptr), on(false), soft(soft_) {
+#ifdef TFNAS_ABLATE
+    prev_skip = g_tfnas_skip;
+    g_tfnas_skip = (ablate_mask() >> id) & 1u;
+#endif
     if (g_mask & (1u << id)) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventRecord(e0, s) == hipSuccess) on = true;
     }
 }
 void ProfScope::stop() {
+#ifdef TFNAS_ABLATE
+    g_tfnas_skip = prev_skip;
+#endif
     if (!on) return;
     on = false;
     hipEvent_t e1;
