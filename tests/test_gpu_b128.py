@@ -2,7 +2,7 @@
 
 The B <= 4 suites exercise every kernel, but the B=128 launches that bench.py times take different code paths (cost-model
 grids, K-split thresholds, prefetching streaming variants, more images than lanes, E-free on cells 0 / 2).  Here:
-  * cells 0, 1, 2, 11, 15 of the supernet at N=128, soft mode and one sampled op, every stage against the CPU oracle;
+  * one cell of every geometry class of the supernet (cells 0, 1, 2, 3, 5, 6, 9, 11, 13, 15, 17) at N=128, soft mode and one sampled op, every stage against the CPU oracle;
   * ONE whole-network teacher-forced alpha-step and w-step at B=128 against the oracle run at the same B=128 (no
     chunking: BN statistics are over the full batch) -- needs ~150 GB of host memory for the oracle's autograd tape;
   * size-independent properties at B=128: bit-determinism of a whole search iteration pair, E-free == materialised E.
@@ -22,9 +22,15 @@ CELLS = {
     0: (16, 24, 2, 'relu', 112),
     1: (24, 24, 1, 'relu', 56),
     2: (24, 40, 2, 'swish', 56),
+    3: (40, 40, 1, 'swish', 28),
+    5: (40, 80, 2, 'swish', 28),
+    6: (80, 80, 1, 'swish', 14),
+    9: (80, 112, 1, 'swish', 14),
     11: (112, 112, 1, 'swish', 14),
+    13: (112, 192, 2, 'swish', 14),
     15: (192, 192, 1, 'swish', 7),
-}
+    17: (192, 320, 1, 'swish', 7),
+}       # one cell of EVERY geometry class of the supernet (round 4: 3, 5, 6, 9, 13, 17 added)
 
 
 def _mem_available_gb():
@@ -63,7 +69,7 @@ def test_cell_soft_mode_at_batch_128(ci):
     print('B=128 cell %d soft: %s' % (ci, {k: v for k, v in res.items() if k.startswith(('relu_', 'kink_', 'fp64_'))}))
 
 
-@pytest.mark.parametrize('ci,idx', [(0, 1), (1, 5), (2, 6), (11, 3), (15, 7)])
+@pytest.mark.parametrize('ci,idx', [(0, 1), (1, 5), (2, 6), (3, 4), (5, 2), (6, 7), (9, 0), (11, 3), (13, 5), (15, 7), (17, 6)])
 def test_cell_sampled_mode_with_weight_grads_at_batch_128(ci, idx):
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     o, m, x, r, e = _cell_inputs(ci)

@@ -155,7 +155,7 @@ def test_whole_net_weight_gradients_incl_stem_and_head(lut):
             continue
         assert b.grad is not None, k
         err, ref = float((b.grad.cpu() - a.grad).abs().max()), float(a.grad.abs().max())
-        assert err <= 2e-5 + 2e-3 * ref, (k, err, ref)
+        assert err <= 2e-5 + 1e-3 * ref, (k, err, ref)
         checked += 1
     assert checked > 60
     o.reset_switches(); m.reset_switches()
@@ -373,7 +373,7 @@ def test_width_sweep_matches_oracle(lut, widths):
         if a.grad is None or k.endswith('log_alphas') or k.endswith('betas'):
             continue
         err, ref = float((b.grad.cpu() - a.grad).abs().max()), float(a.grad.abs().max())
-        assert err <= 2e-5 + 2e-3 * ref, (k, err, ref, inj.flips)
+        assert err <= 2e-5 + 1e-3 * ref, (k, err, ref, inj.flips)
     o.reset_switches(); m.reset_switches()
 
 
