@@ -420,3 +420,27 @@ def test_validate_matches_oracle(lut):
     assert list(wrapped.state_dict().keys())[0].startswith('module.')
     for p in m.parameters():
         assert p.grad is None
+
+
+def test_dropin_model_can_be_copied_and_released_after_a_forward(lut):
+    """The path-level state behind Network.forward (ctypes contexts, streams, arenas) is not part of the module: deepcopy /
+    pickling carry the parameters only, ``close()`` releases it and the next forward rebuilds it with identical results."""
+    import copy
+    import io
+    _, m = _pair(lut)
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    e = torch.empty(18, 8).exponential_(generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        a, _ = m(x, True, 'gumbel', exp_noise=e)
+        m.reset_switches()
+        assert '_pstate' in m.__dict__
+        m2 = copy.deepcopy(m)
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        assert '_pstate' not in m2.__dict__
+        b, _ = m2(x, True, 'gumbel', exp_noise=e)
+        m2.reset_switches()
+        m.close()
+        assert '_pstate' not in m.__dict__
+        c, _ = m(x, True, 'gumbel', exp_noise=e)
+    assert torch.equal(a, b) and torch.equal(a, c)

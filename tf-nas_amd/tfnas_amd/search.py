@@ -96,6 +96,17 @@ class SearchState:
         # arena that would fight over the parameters' storages
         self.model.__dict__['_pstate'] = self
 
+    def release(self):
+        """Drop the path contexts / arenas and the back-reference the model holds (breaks the model <-> state cycle)."""
+        if self.runner is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()            # (kernels of the side streams may still use the arenas)
+            self.runner.close()
+        self.runner = None
+        m = self.model
+        if m is not None and m.__dict__.get('_pstate') is self:
+            m.__dict__.pop('_pstate', None)
+
     # ---- fused optimizer steps (opt_kernels.hip) -------------------------------------------------------------------
     def _bind_momentum(self, opt_w):
         """torch's SGD state and the fused kernel share ONE momentum storage: state[p]['momentum_buffer'] becomes a view of

@@ -7,6 +7,13 @@ every BatchNorm-backward sum table of the backward over the ranks, so all BatchN
 derived network's affine BatchNorms -- use the statistics of the GLOBAL batch: an N-rank run is then the single-GPU run at N
 times the batch.  The reference's analogue is apex's ``convert_syncbn_model`` in the retrain script (train_eval_amp.py:155-157).
 
+EVERY RANK MUST RUN THE SAME BATCH SIZE IN EVERY STEP: the hook averages the (sum, sum of squares) tables over the ranks while the
+kernels keep dividing by the LOCAL element count, which equals the global mean only for equal shards -- and a rank that runs a
+different number of steps (a short last batch, uneven validation shards) leaves the others waiting in the collective.
+``check_equal_batch(n)`` verifies the first condition (one small all-reduce; call it when the batch size can change, e.g. with
+``drop_last=False``).  The hook is removed at interpreter exit and must be removed (``disable()``) before its process group is
+destroyed.
+
 Cost: 6 small all-reduces per cell and direction pair (<= 2 x 1536 doubles each) on the step's critical path -- an opt-in mode,
 not the throughput default.  E-free mode is switched off by the library while the hook is installed.
 """
@@ -61,7 +68,24 @@ def enable(group=None):
     for l in _libs():
         _lib.check(l.tfnas_set_stats_sync(C.cast(cb, C.c_void_p), None, int(world)), 'tfnas_set_stats_sync')
     _STATE.update(cb=cb, group=group, world=world)     # (keeps the ctypes thunk alive)
+    if not _STATE.get('atexit'):
+        import atexit
+        atexit.register(disable)                       # (the thunk must not outlive the interpreter's torch.distributed)
+        _STATE['atexit'] = True
     return True
+
+
+def check_equal_batch(n, device=None):
+    """Raise if the ranks of the hook's group run different batch sizes ``n`` in this step (see the module docstring)."""
+    import torch.distributed as dist
+    if not enabled() or _STATE['world'] == 1:
+        return
+    dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    t = torch.tensor([float(n), -float(n)], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_STATE['group'])
+    hi, lo = float(t[0]), -float(t[1])
+    if hi != lo:
+        raise RuntimeError('tfnas_amd.syncbn: ranks run different batch sizes (%d .. %d); sync-stats needs equal shards' % (lo, hi))
 
 
 def disable():
