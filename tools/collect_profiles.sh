@@ -8,9 +8,9 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $REPO/bench.py --steps 30 --warmup 6 > $OUT/bench_full.json 2> $OUT/bench_full.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dropin --no-width-sweep --no-bf16 --no-retrain > $OUT/stats_run.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-width-sweep --no-bf16 --no-retrain > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-width-sweep --no-bf16 --no-retrain > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dropin --no-width-sweep --no-retrain > $OUT/stats_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-width-sweep --no-retrain > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dropin --no-width-sweep --no-retrain > $OUT/pmc_write.log 2>&1
 # keep the merge small: the raw traces are large
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 find $OUT -name "*agent_info.csv" -delete

@@ -27,7 +27,7 @@ def family(name):
     fam = {'k_dws_fwd': 'k_dw_fwd', 'k_dws_bwd': 'k_dw_bwd_data', 'k_dws_wgrad': 'k_dw_wgrad',
            'k_dwd_fwd': 'k_dw_fwd', 'k_dwd_bwd': 'k_dw_bwd_data', 'k_dwd_wgrad': 'k_dw_wgrad',
            'k_bn2_finish': 'k_bn2_bwd'}.get(fam, fam)
-    if fam == 'k_bn2_pool':
+    if fam in ('k_bn2_pool', 'k_bn2_gather'):
         return 'k_se_pool<bwd>'
     if fam == 'k_se_pool':
         fam += '<bwd>' if m.group(2) and m.group(2).replace(' ', '').endswith(',1>') else '<fwd>'
