@@ -387,22 +387,27 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
     TRY(stats_sync(red2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 1, red2, s));
+    // stride-1 ring cells: the depthwise weight gradient comes out of the backward-data pass below (same dd window, same E
+    // elements: no second read of E, dZ and D -- dw_stream.inc, WGR)
+    const bool dw_fused = d.need_wgrad && dw_bwd_fuses_wgrad(d, b.E);
     if (d.need_wgrad) {
         // ONE fork for the SE and the depthwise weight gradients (every fork is an event record + a stream wait on the
         // host-bound w-step; cells without SE launch nothing for it)
-        hipStream_t sw = fork_to(so, 1, s);
-        if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
-        TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
+        if (d.SE > 0 || !dw_fused) {
+            hipStream_t sw = fork_to(so, 1, s);
+            if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
+            if (!dw_fused) TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
+        }
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
     if (bn || stats_sync_on()) {
         // (unfused: the reduction that also builds cb1 would use the sums before the affine fix / the cross-rank reduction)
-        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, nullptr));
+        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, nullptr, dw_fused));
         TRY(stats_sync(red1, 2 * (size_t)d.M, s));
         if (bn) TRY(bn_bwd_fix(d0, bn, 0, red1, s));
         TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     } else {
-        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1));
+        TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1, dw_fused));
     }
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
     if (b.dx && d.mode != TFNAS_MODE_STEM) {

@@ -762,6 +762,7 @@ static int dw_variant() {
     return v;
 }
 static bool dwd_enabled();
+static bool dwd_bwd_use(const TfnasCellDesc& d);
 static int launch_dw_bwd_data_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                      const float* D, const double* stats2, const double* red2, const float* E,
                                      const double* stats1, float* dEh, double* red1, float* part, hipStream_t s, float* cb1,

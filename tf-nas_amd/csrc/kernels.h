@@ -57,7 +57,10 @@ int launch_expand_stats_gram(const TfnasCellDesc& d, const float* x, double* sta
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
                        const double* red2, const float* E, const float* x, const double* stats1, float* dEh,
-                       double* red1, float* part, hipStream_t s, float* cb1 = nullptr);   // cb1: also fill the BN1 table
+                       double* red1, float* part, hipStream_t s, float* cb1 = nullptr, bool fuse_wgrad = false);
+// true: launch_dw_bwd_data(..., fuse_wgrad = true) also writes the depthwise weight gradients g_dw (stride-1 ring cells: the WGR
+// variant of k_dws_bwd) -- launch_dw_wgrad must then not be called for this cell
+bool dw_bwd_fuses_wgrad(const TfnasCellDesc& d, const float* E);   // cb1: also fill the BN1 table
 int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const double* stats1, double* red1, float* cb1,
                       hipStream_t s);
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
