@@ -70,8 +70,21 @@ def _require_cuda(t, what):
         raise RuntimeError('tfnas_amd: %s must be float32' % what)
 
 
+def _no_plan():
+    return None
+
+
 class CellPlan:
-    """Host-side description of one MixedOP launch: geometry + which candidate blocks take part."""
+    """Host-side description of one MixedOP launch: geometry + which candidate blocks take part.
+
+    A plan is a per-process CACHE (ctypes descriptors with device pointers): copy.deepcopy / pickling of a module that holds one
+    yield None in its place, and the module rebuilds the plan on its next forward."""
+
+    def __reduce__(self):
+        return (_no_plan, ())
+
+    def __deepcopy__(self, memo):
+        return None
 
     def __init__(self, ic, oc, stride, act, blocks, mode=_lib.MODE_CELL):
         self.ic, self.oc, self.stride, self.act = ic, oc, stride, act
