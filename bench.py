@@ -30,6 +30,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -451,6 +452,18 @@ def run_gpu(args):
                          w_step_ms_per_rank=[round(w, 3) for _, w, _ in rows], a_step_ms_per_rank=[round(a, 3) for _, _, a in rows],
                          w_step_ms_spread=round(max(w for _, w, _ in rows) - min(w for _, w, _ in rows), 3),
                          gpu_max_hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'))
+        # replica consistency (tools/dp_check.py's hash): every rank hashes all of its parameters after the
+        # timed region; data-parallel replicas must be bit-identical
+        import hashlib
+        h = hashlib.sha256()
+        for k, p in model.named_parameters():
+            h.update(k.encode())
+            h.update(p.detach().cpu().numpy().tobytes())
+        mine_h = torch.tensor([int(h.hexdigest()[i:i + 8], 16) for i in range(0, 32, 8)], device=dev, dtype=torch.int64)
+        all_h = [torch.zeros_like(mine_h) for _ in range(dist.get_world_size())]
+        dist.all_gather(all_h, mine_h)
+        dist_info['replica_sha256_128'] = h.hexdigest()[:32]
+        dist_info['replicas_bit_identical'] = bool(all(bool((t == all_h[0]).all()) for t in all_h))
 
     # ---- the reference-style loop on the drop-in model (world 1 only: it has no gradient all-reduce)
     dropin = None
@@ -678,6 +691,47 @@ def _attach_pmc_traffic(res):
         pass
 
 
+def visible_devices():
+    """GPUs this process can use (TFNAS_FAKE_DEVICES overrides it: tests of the launcher on CPU-only machines)."""
+    fake = os.environ.get('TFNAS_FAKE_DEVICES')
+    return int(fake) if fake is not None else torch.cuda.device_count()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (the driver's command line; the reference's counterpart is
+    the nn.DataParallel wrap of train_search.py:95,158): re-exec this script under `python -m torch.distributed.run` with one
+    rank per GPU; rank 0 of the child job prints the one JSON line on the inherited stdout.  Fewer than N devices: ONE JSON line
+    carrying "error", exit status 2."""
+    n = args.gpus
+    have = visible_devices()
+    if have < n:
+        print(json.dumps(dict(metric='supernet search images/sec (w-step + alpha-step)', value=None, unit='images/s', n_gpus=n,
+                              error='bench.py --gpus %d: only %d device(s) visible on this node' % (n, have), devices_visible=have)))
+        return 2
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_rank():
+    """TFNAS_BENCH_DRY=1 (tests/test_bench_launch.py): a rank of the self-launched job only proves the rendezvous -- gloo process
+    group, one all-reduce -- and rank 0 prints a JSON line; no GPU is touched."""
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps(dict(dry_run=True, n_gpus=world, ranks_seen=int(t.item()), argv=sys.argv[1:])), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -695,6 +749,11 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(run_cpu_baseline(args.cpu_baseline_only)))
+        return
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))              # `python bench.py --gpus N`: bring up the N ranks ourselves
+    if os.environ.get('TFNAS_BENCH_DRY') == '1':
+        dry_rank()
         return
     res = run_gpu(args)
     if res is not None:

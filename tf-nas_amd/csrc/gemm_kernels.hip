@@ -790,6 +790,9 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
         for (int i = 0; i < 2; ++i) prow[i] = rt * 128 + wrow + 16 * i + lr;
         auto la = [&](int c, int i, int kl) -> f32x4 {
             const int pc = min(prow[i], P - 1), k = min(k0 + kl, klim_a - 4);
+#ifdef TFNAS_HALF_BYTES
+            if (!is_x) return ldS4(dEh, (size_t)pc * ld_a + aoff + k, 0);      // (timing-only build, tfnas_dev.h)
+#endif
             return ld4((is_x ? x : dEh) + (size_t)pc * ld_a + aoff + k);       // wave-uniform select, one unconditional load
         };
         auto xa = [&](f32x4 r, int c, int i, int kl) -> f32x4 {

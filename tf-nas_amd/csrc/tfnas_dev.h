@@ -79,6 +79,42 @@ __device__ __forceinline__ void st4_nt(float* p, f32x4 v) { __builtin_nontempora
 // bytes -- and was removed; `stor` must be 0, the parameter below remains in the signatures of the loaders.)  `idx` is an
 // ELEMENT index, `base` the tensor's base pointer.
 #define TFNAS_STOR(s) 0
+#ifdef TFNAS_HALF_BYTES
+// TIMING-ONLY build (tools/r5_halfbytes.sh): the four stream tensors are stored as the upper halves of
+// their fp32 values (truncation, 8 bytes per quad at byte offset 2 * idx of the SAME buffers) -- every kernel issues the same
+// number of memory instructions for half the bytes.  Wrong numerics by construction; never shipped, never tested for parity.
+typedef unsigned hb_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 hb_expand(hb_u32x2 r) {
+    f32x4 v;
+    v.x = __builtin_bit_cast(float, r.x << 16); v.y = __builtin_bit_cast(float, r.x & 0xffff0000u);
+    v.z = __builtin_bit_cast(float, r.y << 16); v.w = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ hb_u32x2 hb_pack(f32x4 v) {
+    const unsigned a = __builtin_bit_cast(unsigned, v.x), b = __builtin_bit_cast(unsigned, v.y);
+    const unsigned c = __builtin_bit_cast(unsigned, v.z), e = __builtin_bit_cast(unsigned, v.w);
+    return hb_u32x2{(a >> 16) | (b & 0xffff0000u), (c >> 16) | (e & 0xffff0000u)};
+}
+__device__ __forceinline__ const hb_u32x2* hb_ptr(const float* base, size_t idx) {
+    return reinterpret_cast<const hb_u32x2*>(reinterpret_cast<const char*>(base) + 2 * idx);
+}
+__device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int) { return hb_expand(*hb_ptr(base, idx)); }
+__device__ __forceinline__ f32x4 ldS4_raw(const float* base, size_t idx, int) {
+    const hb_u32x2 r = *hb_ptr(base, idx);
+    f32x4 v = {__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y), 0.f, 0.f};
+    return v;
+}
+__device__ __forceinline__ f32x4 ldS4_fin(f32x4 raw, int) {
+    return hb_expand(hb_u32x2{__builtin_bit_cast(unsigned, raw.x), __builtin_bit_cast(unsigned, raw.y)});
+}
+__device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int) {
+    return hb_expand(__builtin_nontemporal_load(hb_ptr(base, idx)));
+}
+__device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int) { *const_cast<hb_u32x2*>(hb_ptr(base, idx)) = hb_pack(v); }
+__device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int) {
+    __builtin_nontemporal_store(hb_pack(v), const_cast<hb_u32x2*>(hb_ptr(base, idx)));
+}
+#else
 __device__ __forceinline__ f32x4 ldS4(const float* base, size_t idx, int) { return ld4(base + idx); }
 // two-phase form for loaders that must not touch the loaded registers before the MFMAs (gemm_core.h)
 __device__ __forceinline__ f32x4 ldS4_raw(const float* base, size_t idx, int) { return ld4(base + idx); }
@@ -86,6 +122,7 @@ __device__ __forceinline__ f32x4 ldS4_fin(f32x4 raw, int) { return raw; }
 __device__ __forceinline__ f32x4 ldS4_nt(const float* base, size_t idx, int) { return ld4_nt(base + idx); }
 __device__ __forceinline__ void stS4(float* base, size_t idx, f32x4 v, int) { st4(base + idx, v); }
 __device__ __forceinline__ void stS4_nt(float* base, size_t idx, f32x4 v, int) { st4_nt(base + idx, v); }
+#endif
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f32x4 splat4(float a) { f32x4 z = {a, a, a, a}; return z; }
