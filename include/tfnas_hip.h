@@ -34,9 +34,10 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): arithmetic modes of the GEMMs (tfnas_set_gemm_mode); the per-group input / output mode of TfnasCellDesc (xg /
+/* 3 (round 5): tfnas_fx_supported (fused per-image route of the late cells).
+ * 2 (round 4): arithmetic modes of the GEMMs (tfnas_set_gemm_mode); the per-group input / output mode of TfnasCellDesc (xg /
  * og), TfnasPathDesc.dual, tfnas_path_set_side_stream2 and tfnas_path_defer_join / tfnas_path_join were measured and removed */
-#define TFNAS_ABI_VERSION 2
+#define TFNAS_ABI_VERSION 3
 #define TFNAS_MAX_GROUPS 8
 #define TFNAS_MAX_SINK 4
 #define TFNAS_MAX_CELLS 32
@@ -160,6 +161,12 @@ int tfnas_cell_ws(const TfnasCellDesc *d, TfnasCellWs *ws);
  * and BN1's batch statistics come from the ic x ic Gram matrix of x).  Currently: TFNAS_MODE_CELL, need_wgrad = 0
  * (the alpha-step: frozen weights), ic in {16, 24, 40}.  Same arithmetic contract as the E path (fp32, <= 1e-3). */
 int tfnas_efree_supported(const TfnasCellDesc *d);
+/* 1 when an E-free launch of the (planned) cell takes the FUSED PER-IMAGE route (csrc/fx_kernels.hip): stride 1, images of at
+ * most 14 x 14 pixels, 64 <= ic <= 192 (a multiple of 16), frozen weights -- the supernet's cells at 14 x 14 and 7 x 7.  One kernel
+ * per direction runs expand 1x1 + BN1 + activation + depthwise k x k (models/layers.py:542-552) for a group of whole images x a
+ * slice of mid channels; neither E nor its gradient is ever written (the dEh buffer of tfnas_mixedop_bwd is used as scratch for
+ * partial sums of dx).  Implies tfnas_efree_supported. */
+int tfnas_fx_supported(const TfnasCellDesc *d);
 
 /* MixedOP forward.
  *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):

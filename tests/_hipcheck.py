@@ -85,6 +85,8 @@ def hip_relu_masks(rec):
     mean2 = (st[ws.off_stats2:ws.off_stats2 + 2 * M].view(M, 2)[:, 0] * (1.0 / (float(N) * Ho * Wo))).float()
     E = None if rec['E'] is None else rec['E'][:N * H * W * M].view(N, H, W, M).cpu()
     D = rec['D'][:N * Ho * Wo * M].view(N, Ho, Wo, M).cpu()
+    if rec.get('fx'):          # fused per-image route: the E buffer holds ehat = (E - mean) * rstd, the value the kernel thresholds
+        mean1 = torch.zeros_like(mean1)
     out = []
     for g in range(d.G):
         off, mc = d.g[g].off, d.g[g].mc
@@ -170,6 +172,9 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad, kink_tau=None, flip_tau=2e-5):
     N, H, W = x.shape[0], x.shape[2], x.shape[3]
     M, Ho, Wo = d.M, d.Ho, d.Wo
     E = saved[2].view(N, H, W, M) if saved[2] is not None else None      # None: E-free mode (frozen weights)
+    # fused per-image route (tfnas_fx_supported; frozen weights): the E buffer holds ehat = BN1(E), the dEh buffer partial sums of dx
+    fx = (not need_wgrad) and bool(_lib.lib().tfnas_fx_supported(C.byref(d)))
+    frec['fx'] = fx
     D = saved[3].view(N, Ho, Wo, M)
     Pr = saved[4].view(len(idxs), N, Ho, Wo, m.out_channels)
     fsmall = saved[5]
@@ -212,14 +217,17 @@ def compare_cell(o, m, x, r, e, idxs, need_wgrad, kink_tau=None, flip_tau=2e-5):
             km = km4.permute(0, 2, 3, 1)
             pk = km4.any(1, keepdim=True)
             pix_kink = pk if pix_kink is None else (pix_kink | pk)
-        if E is not None:
+        if E is not None and fx:
+            res[tag + 'Eh'] = err(E[..., off:off + mc], nhwc(det['Eh']))
+        elif E is not None:
             res[tag + 'E'] = err(E[..., off:off + mc], nhwc(det['E']))
         res[tag + 'D'] = err(D[..., off:off + mc], nhwc(det['D']))
         if 'gate' in det:
             res[tag + 'gate'] = err(gate[:, off:off + mc], det['gate'].flatten(1))
         res[tag + 'Pr'] = err(Pr[g], nhwc(det['P']))
         res[tag + 'dZ'] = err(dZ[..., off:off + mc], nhwc(det['Z'].grad))
-        res[tag + 'dEh'] = err(dEh[..., off:off + mc], nhwc(det['Eh'].grad), km)
+        if not fx:
+            res[tag + 'dEh'] = err(dEh[..., off:off + mc], nhwc(det['Eh'].grad), km)
     res['out'] = err(out_m, out_o)
     res['dx'] = err(xm.grad, xo.grad, pix_kink)
     if pix_kink is not None:

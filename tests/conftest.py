@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, 'tf-nas_amd'), os.path.join(ROOT, 'oracle'), 
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+# the fused per-image route of the late cells (csrc/fx_kernels.hip) is exercised by the whole GPU suite, whatever the library's default
+os.environ.setdefault('TFNAS_FX', '1')
 
 
 def pytest_configure(config):

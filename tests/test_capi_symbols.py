@@ -36,7 +36,7 @@ def test_header_functions_are_all_exported_and_bound(lib):
 
 def test_struct_layouts(lib):
     from tfnas_amd import _lib
-    assert lib.tfnas_abi_version() == 2
+    assert lib.tfnas_abi_version() == 3
     assert lib.tfnas_sizeof(0) == C.sizeof(_lib.TfnasGroup)
     assert lib.tfnas_sizeof(1) == C.sizeof(_lib.TfnasCellDesc)
     assert lib.tfnas_sizeof(2) == C.sizeof(_lib.TfnasCellWs)

@@ -240,6 +240,9 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     } while (0)
 
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
+extern "C" int tfnas_fx_supported(const TfnasCellDesc* dp) {
+    return (dp && dp->mode == TFNAS_MODE_CELL && !dp->need_wgrad && !efree_ic_small(dp->ic) && fx_supported(*dp)) ? 1 : 0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // One cell, forward / backward: the launch sequences shared by the per-cell entry points below and by the path level
@@ -271,12 +274,17 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
     TfnasCellDesc dc = d0;
     if (bn) dc.eps = -1.f;
     const TfnasCellDesc& d = dc;
-    if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));          // 1x1 expand (all groups) + BN1 statistics
+    // E-free late cells (14 x 14 / 7 x 7 images, 64..192 input channels): the fused per-image route (fx_kernels.hip)
+    // (frozen weights only: fx_supported refuses need_wgrad; with E the forward leaves ehat there for the backward)
+    const bool fx = !bn && fx_supported(d);
+    if (fx) TRY(launch_fx_stats(d, b.x, stats1, b.part, s));                  // BN1 statistics from the Gram matrix of x
+    else if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));     // 1x1 expand (all groups) + BN1 statistics
     else TRY(launch_expand_stats_gram(d, b.x, stats1, b.part, s));            // E-free: BN1 statistics from the Gram matrix of x
     const bool sync = !(bn && bn->eval);          // (eval mode normalises with the running statistics: nothing to reduce)
     if (sync) TRY(stats_sync(stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
     if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
-    TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));          // BN1+act fused load, depthwise, BN2 statistics
+    if (fx) TRY(launch_fx_fwd(d, b.x, stats1, b.E, b.D, stats2, b.part, s));  // expand + BN1 + act + depthwise in one kernel
+    else TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));     // BN1+act fused load, depthwise, BN2 statistics
     if (sync) TRY(stats_sync(stats2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));
     TRY(launch_se_pool(d, b.D, stats2, pooled, s));                           // SE squeeze (SE groups only)
@@ -387,6 +395,18 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
     TRY(stats_sync(red2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 1, red2, s));
+    if (!bn && fx_supported(d)) {
+        // fused per-image route: depthwise dgrad + act' + the dE (rstd . W1) term of the expand dgrad in one kernel (dE never
+        // materialised; partial sums per channel slice in the dEh buffer), then the BN1-backward correction -x G + b
+        int nsl = 0;
+        TRY(launch_fx_bwd(d, b.x, b.E, stats1, stats2, red2, b.dZ, b.D, gate, dpooled, b.dEh, (size_t)ws.dEh, red1, cb1, part, &nsl, s));
+        if (b.dx) {
+            float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
+            TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
+            TRY(launch_expand_dgrad_x(d, b.x, cb1, gram, dout_res, b.wmix, b.dx, b.dEh, nsl, s, b.add_src, b.add_scale));
+        }
+        return 0;
+    }
     // stride-1 ring cells: the depthwise weight gradient comes out of the backward-data pass below (same dd window, same E
     // elements: no second read of E, dZ and D -- dw_stream.inc, WGR)
     const bool dw_fused = d.need_wgrad && dw_bwd_fuses_wgrad(d, b.E);

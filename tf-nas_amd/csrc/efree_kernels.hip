@@ -134,12 +134,19 @@ __global__ __launch_bounds__(256) void k_stats1_gram(TfnasCellDesc d, const doub
 }
 
 bool efree_supported(const TfnasCellDesc& d) {
-    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad || !efree_ic_ok(d.ic)) return false;
+    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
+    if (!efree_ic_ok(d.ic)) return fx_supported(d);            // late cells: the fused per-image route (fx_kernels.hip)
     if (stats_sync_on()) return false;          // (cross-rank statistics are reduced on the (sum, sumsq) tables of E)
     if ((size_t)d.N * d.H * d.W * d.ic >= ((size_t)1 << 31)) return false;
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].k != 3 && d.g[g].k != 5) return false;
     return true;
+}
+
+int launch_x_colsum(const float* x, int P, int ic, int rps, int nb, float* part, hipStream_t s) {
+    ProfScope _prof(TK_EXPAND_FWD, s);
+    hipLaunchKernelGGL(k_x_colsum, dim3(nb), dim3(256), 0, s, x, P, ic, rps, part);
+    return (int)hipGetLastError();
 }
 
 // scratch: `part` rows [nb][ic*ic] from the bottom; the double results sx[ic] | C[ic*ic] in the top of the buffer

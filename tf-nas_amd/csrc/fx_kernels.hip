@@ -1,0 +1,1223 @@
+// Fused per-image route of the late cells ("fx"; fx.h): expand 1x1 -> BN1 -> act -> depthwise k x k in ONE kernel per direction,
+// the expanded tensor E and its gradient never leave the compute unit.
+//
+// Reference arithmetic: inverted_bottleneck + depth_conv of MBInvertedResBlock.forward (models/layers.py:542-552; the modules are
+// built at layers.py:463-507) and their autograd backward; BatchNorm = batch statistics, no affine (layers.py:469,498).
+//
+// Why this shape (measured): halving the bytes of every stream tensor leaves the alpha-step unchanged --
+// the materialise-once kernels are bound by instructions and latency (ring loaders, LDS-staged GEMM epilogues, K loops of 5-12
+// chunks with a DRAM round trip each), not by HBM.  So the fused kernels are built around instruction count:
+//   * a workgroup (8 waves) owns NI whole images x a slice of mid channels; the images' x rows are split ONCE into three bf16
+//     planes and stay in registers as MFMA B operands for the workgroup's life (x: [pixels][ic], ic = 80..192);
+//   * the expand weights arrive pre-split (k_fx_pack: one "blob" per 32-channel chunk = W1 planes in the A-operand layout + BN1
+//     constants + depthwise taps), copied to LDS one chunk ahead -- no operand is loaded from memory inside the MFMA loop;
+//   * C = W1_chunk x^T puts 4 consecutive CHANNELS of one pixel in a lane: BN1 + activation and one ds_write_b128 drop it
+//     into the [pixel][32 channel] LDS tile the stencil reads (zero halo written once; the whole image is resident: no halo
+//     recompute, no ring, no per-row bookkeeping);
+//   * forward: one barrier per chunk; inside an interval the two waves of a SIMD run the stencil of chunk i and the MFMAs of
+//     chunk i + 1 in opposite order (matrix pipe beside LDS / VALU);
+//   * backward: dd = BN2-backward(dZ, D) -> LDS, stencil with flipped taps, dE = . * act'(ehat) written back into the LDS tile that
+//     held ehat, and that tile is the B operand of the expand-dgrad MFMA (A = rstd (.) W1 planes from the blob): dx partial sums
+//     accumulate in registers over the slice; BN1-backward sums t1, t2 come out of the same pass (the correction operator
+//     -x G + b of k_expand_dgrad is applied afterwards, it is linear in them).
+#include "tfnas_dev.h"
+#include "kernels.h"
+#include "prof.h"
+#include "fx.h"
+#include "gemm_x3.h"
+
+// ---------------------------------------------------------------------------------------------------------------- plan
+static int fx_ks(int ic) { return (ic + 31) / 32; }
+
+bool fx_plan(const TfnasCellDesc& d, FxPlan& pl, bool bwd) {
+    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
+    if (stats_sync_on()) return false;                     // (BN1 statistics come from the Gram matrix of x: efree_kernels.hip)
+    if (d.ic < 64 || d.ic > 192 || (d.ic & 15)) return false;
+    if (d.stride != 1) return false;                       // (stride-2 cells keep the materialised route)
+    const int HW = d.H * d.W;
+    if (HW > 196 || d.W < 4) return false;
+    const int KS = fx_ks(d.ic);
+    int NI = 128 / HW;                                      // several small images per workgroup: one pixel tile per wave
+    if (NI < 1) NI = 1;
+    if (NI > 4) NI = 4;
+    if (NI > d.N) NI = d.N;
+    const int ntiles = (NI * HW + 15) / 16, RT = (ntiles + 7) / 8;
+    if (RT * KS > 8) return false;                          // register budget of the x planes: 12 * RT * KS VGPRs
+    if (NI * ((d.Wo + 3) / 4) * d.Ho > 64) return false;    // one stencil item (4-pixel strip x channel quad) per thread
+    pl.KS = KS; pl.RT = RT; pl.NI = NI;
+    pl.nig = (d.N + NI - 1) / NI;
+    pl.RS = 64 * KS + 32;
+    int kmax = 3;
+    for (int g = 0; g < d.G; ++g) {
+        if (d.g[g].k != 3 && d.g[g].k != 5) return false;
+        if (d.g[g].k > kmax) kmax = d.g[g].k;
+    }
+    pl.KMAX = kmax;
+    pl.PB = 96 * pl.RS + 256;                               // 3 planes x 32 channels | (mean, rstd) x 32
+    pl.WB = 25 * 128;                                       // taps [k*k][32] (room for 5 x 5)
+    pl.XB = bwd ? 512 + 3 * d.ic * 64 : 0;                  // cst2 [32] x 4 | rstd (.) W1 planes [3][ic][32 channels]
+    pl.BLOB = (pl.PB + pl.WB + pl.XB + 255) & ~255;
+    // chunks and slices: a slice never crosses a group (one kernel size per workgroup)
+    int nch = 0;
+    for (int g = 0; g < d.G; ++g) nch += (d.g[g].mcp + 31) / 32;
+    pl.nchunks = nch;
+    if (nch > 32000) return false;
+    const int target_wgs = bwd ? 640 : 1280;
+    int want = (target_wgs + pl.nig - 1) / pl.nig;
+    if (bwd) {                                              // every slice leaves a [P][ic] partial of dx in the cell's dEh buffer
+        const int room = d.M / d.ic - 1 - d.G;              // (.. [P][M] floats; - G: rounding of the per-group split below)
+        if (want > room) want = room;
+    }
+    if (want < 1) want = 1;
+    int cps = (nch + want - 1) / want;                      // chunks per slice
+    if (cps < (bwd ? 6 : 3)) cps = bwd ? 6 : 3;
+    int ns = 0, chunk0 = 0;
+    for (int g = 0; g < d.G; ++g) {
+        const int ng = (d.g[g].mcp + 31) / 32;
+        const int parts = (ng + cps - 1) / cps;
+        for (int p = 0; p < parts; ++p) {
+            if (ns >= FX_MAX_SLICES) return false;
+            const int a = (int)((long)ng * p / parts), b = (int)((long)ng * (p + 1) / parts);
+            pl.sl[ns].g = (int16_t)g;
+            pl.sl[ns].c0 = (int16_t)(32 * a);
+            pl.sl[ns].nch = (int16_t)(b - a);
+            pl.sl[ns].chunk0 = (int16_t)(chunk0 + a);
+            ++ns;
+        }
+        chunk0 += ng;
+    }
+    pl.nslices = ns;
+    return true;
+}
+
+// LDS bytes of the forward kernel: two image tiles, two plane buffers, two tap buffers, two statistics buffers
+static size_t fx_fwd_lds(const TfnasCellDesc& d, const FxPlan& pl) {
+    const int PAD = pl.KMAX / 2, HP = d.H + 2 * PAD, WP = (d.W + 2 * PAD) | 1;
+    const size_t tile = (size_t)(pl.NI * HP * WP + 8) * 128;
+    return 2 * tile + 2 * (size_t)pl.PB + 2 * (size_t)pl.WB + 2 * 2048;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pack
+// blob[chunk] = | W1 planes h, m, l: [32 channels][RS bytes] bf16, k < 32 KS, zeros beyond ic / mc | cst1 [32] (mean, rstd) |
+//               | taps [k*k][32] | (backward) cst2 [32] (mean2, rstd2, R1/Po, R2/Po) | Wr planes [3][ic][64 B, k-group swizzled] |
+// Wr[c][ch] = rstd1[ch] * W1[ch][c]: the A operand of the expand dgrad (rows = input channels, k = the chunk's 32 mid channels);
+// 16-byte group q of row c is stored at group q ^ fx_swz(c) -- conflict-free ds_read_b128 without padding (fx.h).
+__device__ __host__ __forceinline__ int fx_swz(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }   // 0, 3, 2, 1
+
+__device__ __forceinline__ void fx_split3(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const unsigned hb = x3_bits(v);
+    const float r1 = v - x3_float(hb & 0xffff0000u);
+    const unsigned mb = x3_bits(r1);
+    const float r2 = r1 - x3_float(mb & 0xffff0000u);
+    h = (unsigned short)(hb >> 16);
+    m = (unsigned short)(mb >> 16);
+    l = (unsigned short)(x3_bits(r2) >> 16);
+}
+
+__global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, const double* __restrict__ stats1,
+                                                 const double* __restrict__ stats2, const double* __restrict__ red2,
+                                                 unsigned char* __restrict__ blob) {
+    const int chunk = blockIdx.x, tid = threadIdx.x;
+    int si = 0;
+    for (; si < pl.nslices - 1; ++si)
+        if (chunk < pl.sl[si + 1].chunk0) break;
+    const int g = pl.sl[si].g, c0 = pl.sl[si].c0 + 32 * (chunk - pl.sl[si].chunk0);
+    const int mc = d.g[g].mc, off = d.g[g].off, ic = d.ic, K = d.g[g].k, KK = K * K;
+    const int RS = pl.RS, KP = 32 * pl.KS;
+    unsigned char* b = blob + (size_t)chunk * pl.BLOB;
+    const float* __restrict__ w1 = d.g[g].w_expand;
+    __shared__ float2 cst[32];
+    if (tid < 32) {
+        float2 c = make_float2(0.f, 0.f);
+        if (c0 + tid < mc) c = bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * d.H * d.W), d.eps);
+        cst[tid] = c;
+        reinterpret_cast<float2*>(b + 96 * RS)[tid] = c;
+    }
+    for (int e = tid; e < 32 * KP; e += 256) {
+        const int ch = e / KP, k = e - ch * KP;
+        const float v = (c0 + ch < mc && k < ic) ? w1[(size_t)(c0 + ch) * ic + k] : 0.f;
+        unsigned short h, m, l;
+        fx_split3(v, h, m, l);
+        unsigned short* row = reinterpret_cast<unsigned short*>(b + ch * RS) + k;
+        row[0] = h;
+        row[16 * RS] = m;            // (+ 32 rows of RS bytes = 16 RS shorts)
+        row[32 * RS] = l;
+    }
+    float* taps = reinterpret_cast<float*>(b + pl.PB);
+    for (int e = tid; e < KK * 32; e += 256) {
+        const int t = e >> 5, ch = e & 31;
+        taps[e] = (c0 + ch < mc) ? d.g[g].w_dw[(size_t)(c0 + ch) * KK + t] : 0.f;
+    }
+    if (pl.XB) {
+        f32x4* c2 = reinterpret_cast<f32x4*>(b + pl.PB + pl.WB);
+        if (tid < 32) {
+            f32x4 t = zero4();
+            if (c0 + tid < mc) {
+                const double inv = 1.0 / ((double)d.N * d.Ho * d.Wo);
+                const float2 c = bn_consts(stats2 + 2 * (size_t)(off + c0 + tid), inv, d.eps);
+                t.x = c.x;
+                t.y = c.y;
+                t.z = (float)(red2[2 * (size_t)(off + c0 + tid) + 0] * inv);
+                t.w = (float)(red2[2 * (size_t)(off + c0 + tid) + 1] * inv);
+            }
+            c2[tid] = t;
+        }
+        __syncthreads();
+        unsigned char* wr = b + pl.PB + pl.WB + 512;
+        for (int e = tid; e < 32 * ic; e += 256) {
+            const int ch = e / ic, c = e - ch * ic;          // (reads of W1 rows stay coalesced)
+            const float v = (c0 + ch < mc) ? cst[ch].y * w1[(size_t)(c0 + ch) * ic + c] : 0.f;
+            unsigned short h, m, l;
+            fx_split3(v, h, m, l);
+            const int grp = (ch >> 3) ^ fx_swz(c);
+            unsigned short* p = reinterpret_cast<unsigned short*>(wr + c * 64 + grp * 16) + (ch & 7);
+            p[0] = h;
+            p[ic * 32] = m;          // plane stride ic * 64 bytes
+            p[ic * 64] = l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- shared pieces
+typedef unsigned char u8;
+
+template <int KS, int RT>
+struct FxX {                       // the workgroup's x rows as MFMA B operands: pixel = column, k = input channel
+    bf16x8 h[RT][KS], m[RT][KS], l[RT][KS];
+};
+
+__device__ __forceinline__ void fx_split8(f32x4 a, f32x4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const X3Planes pa = x3_split4<6>(a), pb = x3_split4<6>(b);
+    h = __builtin_bit_cast(bf16x8, u32x4{pa.h.x, pa.h.y, pb.h.x, pb.h.y});
+    m = __builtin_bit_cast(bf16x8, u32x4{pa.m.x, pa.m.y, pb.m.x, pb.m.y});
+    l = __builtin_bit_cast(bf16x8, u32x4{pa.l.x, pa.l.y, pb.l.x, pb.l.y});
+}
+
+// six products of the split operands, smallest terms first (gemm_x3.h)
+#define FX_MFMA6(acc, ah, am, al, bh, bm, bl)                                   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc, 0, 0, 0);        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+
+// copy `bytes` (multiple of 16) from global to LDS with all FX_THREADS threads: loads now, stores later (two-phase)
+template <int NV>
+struct FxCopy {
+    u32x4 v[NV];
+    // (every lane always loads -- from a clamped offset: a predicated load leaves a select on the destination registers, and
+    //  the compiler then waits for ALL outstanding memory traffic right behind the load instead of at the store below)
+    __device__ __forceinline__ void load(const u8* __restrict__ src, int bytes) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = (threadIdx.x + i * FX_THREADS) * 16;
+            v[i] = *reinterpret_cast<const u32x4*>(src + (o < bytes ? o : bytes - 16));
+        }
+    }
+    __device__ __forceinline__ void store(u8* dst, int bytes) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int o = (threadIdx.x + i * FX_THREADS) * 16;
+            if (o < bytes) *reinterpret_cast<u32x4*>(dst + o) = v[i];
+        }
+    }
+};
+
+// one of the six split products on every (channel tile, pixel tile) accumulator of the wave: consecutive MFMAs never share an
+// accumulator (a dependent v_mfma_f32_16x16x32_bf16 cannot issue before its predecessor has left the pipe)
+// (no condition around an MFMA, however uniform: every `if` is a scalar compare + branch and a basic-block boundary the
+//  scheduler cannot move MFMAs across -- the first version, with `if (tile exists)` around each one, ran 4x slower than its
+//  instruction counts; tiles past the end of the workgroup's pixels multiply zero x planes instead)
+#define FX_TERM(A_, B_)                                                                                                  \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) _Pragma("unroll") for (int pt = 0; pt < RT; ++pt)                   \
+        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[ct], X.B_[pt][ks], acc[ct][pt], 0, 0, 0);
+
+// e = BN1(x W1_chunk^T) for the wave's pixel tiles: A = W1 planes (LDS blob), B = x planes (registers).  Lane (n, q) of tile
+// (ct, pt) ends up with channels 16 ct + 4 q .. + 3 of pixel 16 (wave + 8 pt) + n; OUT = 0 / 1: act(e) -> tile, 2: e -> tile.
+// eg != nullptr: e (normalised, before the activation) also goes to global memory, eg[pixel * M + channel] (what the backward
+// of the stored-ehat mode reads back; egoff[pt] = the pixel's row offset, chlim = valid channels of the chunk).
+template <int KS, int RT, int OUT>
+__device__ __forceinline__ void fx_expand(const u8* P, const FxX<KS, RT>& X, float* tile, const int (&slot)[RT],
+                                          const bool (&pv)[RT], int ntiles, float* __restrict__ eg = nullptr,
+                                          const size_t* egoff = nullptr, int chlim = 0) {
+    constexpr int RS = 64 * KS + 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    f32x4 acc[2][RT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < RT; ++pt) acc[ct][pt] = zero4();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const u8* ap = P + (16 * ct + n) * RS + 64 * ks + 16 * q;
+            ah[ct] = *reinterpret_cast<const bf16x8*>(ap);
+            am[ct] = *reinterpret_cast<const bf16x8*>(ap + 32 * RS);
+            al[ct] = *reinterpret_cast<const bf16x8*>(ap + 64 * RS);
+        }
+        FX_TERM(al, h) FX_TERM(am, m) FX_TERM(ah, l) FX_TERM(am, h) FX_TERM(ah, m) FX_TERM(ah, h)     // smallest terms first
+    }
+    const float2* cst = reinterpret_cast<const float2*>(P + 96 * RS);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        float2 c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = cst[16 * ct + 4 * q + r];
+#pragma unroll
+        for (int pt = 0; pt < RT; ++pt) {
+            // (pixels past the end carry a spare slot of the tile: the LDS store is unconditional)
+            f32x4 e, v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = (acc[ct][pt][r] - c[r].x) * c[r].y;
+                v[r] = OUT == 2 ? e[r] : act_f<(OUT == 2 ? 0 : OUT)>(e[r]);
+            }
+            st4(tile + slot[pt] * 32 + 16 * ct + 4 * q, v);
+            // (columns between mc and the chunk's end are the group's padding in the [pixels][M] row: zeros may go there)
+            if (eg && pv[pt]) st4_nt(eg + egoff[pt] + 16 * ct + 4 * q, e);
+        }
+    }
+}
+
+// sum a per-thread (sum, sumsq) quad pair over the 8 strips of a wave (lanes sharing lane & 7) and park the wave's totals
+__device__ __forceinline__ void fx_stat_park(f32x4 a, f32x4 b, float* stat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] += __shfl_xor(a[r], o, 64);
+            b[r] += __shfl_xor(b[r], o, 64);
+        }
+    }
+    if (lane < 8) {
+        st4(stat + wave * 64 + 4 * lane, a);
+        st4(stat + wave * 64 + 32 + 4 * lane, b);
+    }
+}
+// threads 0..63: total of the 8 waves -> this workgroup's partial row (row = image group), fixed order
+__device__ __forceinline__ void fx_stat_emit(const float* stat, float* __restrict__ prow, int c0, int mcp) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int ch = tid & 31, which = tid >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += stat[w * 64 + which * 32 + ch];
+        if (c0 + ch < mcp) prow[2 * (size_t)(c0 + ch) + which] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+template <int K, int ACT, int KS, int RT>
+__device__ __forceinline__ void fx_fwd_stencil(const float* tile, const float* taps, const TfnasCellDesc& d, int HP, int WP,
+                                               int nimg, int img0, int goff, int c0, int mcp, float* __restrict__ D, float* stat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = lane & 7, k8 = lane >> 3;
+    const int Ho = d.Ho, Wo = d.Wo, M = d.M;
+    const int SCN = (Wo + 3) >> 2, per_img = SCN * Ho, nstrips = nimg * per_img;
+    const bool chok = c0 + 4 * cq < mcp;
+    f32x4 ssum = zero4(), ssq = zero4();
+    for (int j = wave * 8 + k8; j < nstrips; j += 64) {
+        const int img = j / per_img, r = j - img * per_img, sc = r / Ho, oh = r - sc * Ho, ow0 = 4 * sc;
+        const float* base = tile + ((img * HP + oh) * WP + ow0) * 32 + 4 * cq;
+        f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const float* rowp = base + ky * WP * 32;
+            const float* wp = taps + ky * K * 32 + 4 * cq;
+            f32x4 win[K + 3];
+#pragma unroll
+            for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 wv = ld4(wp + kx * 32);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
+            }
+        }
+        if (chok) {
+            const int npx = Wo - ow0 < 4 ? Wo - ow0 : 4;
+            float* __restrict__ o = D + ((size_t)((img0 + img) * Ho + oh) * Wo + ow0) * M + goff + c0 + 4 * cq;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj < npx) {
+                    st4_nt(o + (size_t)jj * M, acc[jj]);
+                    ssum += acc[jj];
+                    ssq += acc[jj] * acc[jj];
+                }
+            }
+        }
+    }
+    fx_stat_park(ssum, ssq, stat);
+}
+
+template <int K, int ACT, int KS, int RT>
+__device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan& pl, const float* __restrict__ x,
+                                            const u8* __restrict__ blob, float* __restrict__ D, float* __restrict__ part,
+                                            u8* lds, int ig, const FxSlice sl, float* __restrict__ Eg) {
+    constexpr int PAD = K / 2, RS = 64 * KS + 32, PB = 96 * RS + 256, WBK = K * K * 128;
+    constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16), NVW = 1;
+    static_assert(WBK <= FX_THREADS * 16, "tap blob copy");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M;
+    const int HP = H + 2 * PAD, WP = (W + 2 * PAD) | 1;
+    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW, ntiles = (NPX + 15) >> 4;
+    const int g = sl.g, mcp = d.g[g].mcp, goff = d.g[g].off, nch = sl.nch;
+    // LDS carve-up (sized on the host for the cell's largest kernel size)
+    const int PADM = pl.KMAX / 2;
+    const size_t tile_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
+    float* T[2] = {reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds + tile_b)};
+    u8* Pb[2] = {lds + 2 * tile_b, lds + 2 * tile_b + pl.PB};
+    u8* Wb[2] = {lds + 2 * tile_b + 2 * pl.PB, lds + 2 * tile_b + 2 * pl.PB + pl.WB};
+    float* St[2] = {reinterpret_cast<float*>(lds + 2 * tile_b + 2 * pl.PB + 2 * pl.WB),
+                    reinterpret_cast<float*>(lds + 2 * tile_b + 2 * pl.PB + 2 * pl.WB + 2048)};
+
+    // pixels of the wave's tiles: LDS slot (padded image coordinates) and validity
+    int slot[RT];
+    bool pv[RT];
+    size_t egoff[RT];                                  // stored-ehat mode: the pixel's row in the [pixels][M] tensor
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        const int p = 16 * (wave + 8 * pt) + n;
+        pv[pt] = p < NPX;
+        const int img = p / HW, r = p - img * HW, h = r / W, w = r - h * W;
+        slot[pt] = pv[pt] ? (img * HP + h + PAD) * WP + w + PAD : pl.NI * (H + 2 * (pl.KMAX / 2)) * ((W + 2 * (pl.KMAX / 2)) | 1) + 4;
+        egoff[pt] = ((size_t)img0 * HW + p) * M + goff;
+    }
+    // x rows -> split planes (registers, once)
+    FxX<KS, RT> X;
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        const int p = 16 * (wave + 8 * pt) + n;
+        const float* __restrict__ xp = x + ((size_t)img0 * HW + p) * ic + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool ok = pv[pt] && 32 * ks + 8 * q < ic;
+            const f32x4 a = ok ? ld4(xp + 32 * ks) : zero4(), b = ok ? ld4(xp + 32 * ks + 4) : zero4();
+            fx_split8(a, b, X.h[pt][ks], X.m[pt][ks], X.l[pt][ks]);
+        }
+    }
+    // zero both image tiles (the halo stays zero; interiors are rewritten per chunk)
+    for (size_t i = (size_t)tid * 16; i < 2 * tile_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    {
+        FxCopy<NVP> cp;
+        FxCopy<NVW> cw;
+        cp.load(bl0, PB);
+        cw.load(bl0 + pl.PB, WBK);
+        cp.store(Pb[0], PB);
+        cw.store(Wb[0], WBK);
+        if (nch > 1) {
+            cp.load(bl0 + pl.BLOB, PB);
+            cp.store(Pb[1], PB);
+        }
+    }
+    __syncthreads();
+    fx_expand<KS, RT, ACT>(Pb[0], X, T[0], slot, pv, ntiles, Eg ? Eg + sl.c0 : nullptr, egoff, mcp - sl.c0);
+    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+    for (int i = 0; i < nch; ++i) {
+        // interval i: stencil of chunk i  ||  MFMAs of chunk i + 1;  planes of chunk i + 2 and taps of chunk i + 1 on their way
+        FxCopy<NVP> cp;
+        FxCopy<NVW> cw;
+        const bool p2 = i + 2 < nch, w1 = i + 1 < nch;
+        cp.load(bl0 + (size_t)(p2 ? i + 2 : i) * pl.BLOB, PB);              // (always issued: see FxCopy)
+        cw.load(bl0 + (size_t)(w1 ? i + 1 : i) * pl.BLOB + pl.PB, WBK);
+        __syncthreads();
+        if (i > 0) fx_stat_emit(St[(i - 1) & 1], prow, sl.c0 + 32 * (i - 1), mcp);
+        const int c0 = sl.c0 + 32 * i;
+        if (wave < 4) {
+            fx_fwd_stencil<K, ACT, KS, RT>(T[i & 1], reinterpret_cast<const float*>(Wb[i & 1]), d, HP, WP, nimg, img0, goff, c0,
+                                           mcp, D, St[i & 1]);
+            if (w1) fx_expand<KS, RT, ACT>(Pb[(i + 1) & 1], X, T[(i + 1) & 1], slot, pv, ntiles, Eg ? Eg + c0 + 32 : nullptr, egoff, mcp - c0 - 32);
+        } else {
+            if (w1) fx_expand<KS, RT, ACT>(Pb[(i + 1) & 1], X, T[(i + 1) & 1], slot, pv, ntiles, Eg ? Eg + c0 + 32 : nullptr, egoff, mcp - c0 - 32);
+            fx_fwd_stencil<K, ACT, KS, RT>(T[i & 1], reinterpret_cast<const float*>(Wb[i & 1]), d, HP, WP, nimg, img0, goff, c0,
+                                           mcp, D, St[i & 1]);
+        }
+        if (p2) cp.store(Pb[i & 1], PB);
+        if (w1) cw.store(Wb[(i + 1) & 1], WBK);
+    }
+    __syncthreads();
+    fx_stat_emit(St[(nch - 1) & 1], prow, sl.c0 + 32 * (nch - 1), mcp);
+}
+
+template <int ACT, int KS, int RT>
+__global__ __launch_bounds__(FX_THREADS) void k_fx_fwd(TfnasCellDesc d, FxPlan pl, const float* __restrict__ x,
+                                                       const u8* __restrict__ blob, float* __restrict__ D,
+                                                       float* __restrict__ part, float* __restrict__ Eg) {
+    extern __shared__ __attribute__((aligned(16))) u8 fx_lds[];
+    // consecutive workgroups = the image groups of ONE slice: they read the same blobs (L2) at about the same time
+    const int si = blockIdx.x / pl.nig, ig = blockIdx.x - si * pl.nig;
+    const FxSlice sl = pl.sl[si];
+    if (d.g[sl.g].k == 3) fx_fwd_body<3, ACT, KS, RT>(d, pl, x, blob, D, part, fx_lds, ig, sl, Eg);
+    else fx_fwd_body<5, ACT, KS, RT>(d, pl, x, blob, D, part, fx_lds, ig, sl, Eg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+// One stencil item per thread (4-pixel strip x channel quad), the same for every chunk: worked out once.
+struct FxItem {
+    int toff;        // float offset of the window's top-left pixel in the padded image tile (+ 4 cq)
+    int eoff;        // float offset of the strip's first pixel in the compact [pixel][32] tile (+ 4 cq)
+    int npx;         // valid pixels of the strip; 0: no item
+};
+
+// dd = BN2-backward of dZ (dwconv_kernels.hip: bn2_dd): cst2[c] = (mean2, rstd2, R1/Po, R2/Po)
+template <int ACT>
+__device__ __forceinline__ f32x4 fx_bn2_dd(const f32x4* cst2, f32x4 dz, f32x4 dv, bool has_se, f32x4 gate4, f32x4 dpool4) {
+    f32x4 r;
+    if (has_se) dz = dz * gate4 + dpool4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = cst2[j];
+        const float dh = (dv[j] - t.x) * t.y;
+        const float ddh = dz[j] * act_d<ACT>(dh);
+        r[j] = t.y * (ddh - t.z - dh * t.w);
+    }
+    return r;
+}
+
+template <int K, int ACT>
+__device__ __forceinline__ void fx_bwd_stencil(const float* dd, const float* taps, float* eh, const FxItem it, int WP, float* stat) {
+    const int lane = threadIdx.x & 63, cq = lane & 7;
+    f32x4 t1 = zero4(), t2 = zero4();
+    if (it.npx > 0) {
+        const float* base = dd + it.toff;
+        f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const float* rowp = base + ky * WP * 32;
+            const float* wp = taps + (K * K - 1 - ky * K) * 32 + 4 * cq;          // flipped taps
+            f32x4 win[K + 3];
+#pragma unroll
+            for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 wv = ld4(wp - kx * 32);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj < it.npx) {
+                float* ep = eh + it.eoff + jj * 32;
+                const f32x4 e = ld4(ep);
+                f32x4 de;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    de[r] = acc[jj][r] * act_d<ACT>(e[r]);
+                    t1[r] += de[r];
+                    t2[r] += de[r] * e[r];
+                }
+                st4(ep, de);
+            }
+        }
+    }
+    fx_stat_park(t1, t2, stat);
+}
+
+// LDS bytes of the backward kernel: ehat / dE tile x 2, dd image tile, plane buffer, Wr buffer, cst2, taps x 2, statistics
+static size_t fx_bwd_lds(const TfnasCellDesc& d, const FxPlan& pl) {
+    const int PAD = pl.KMAX / 2, HP = d.H + 2 * PAD, WP = (d.W + 2 * PAD) | 1;
+    const size_t eh = (size_t)(((pl.NI * d.H * d.W + 15) / 16) * 16 + 16) * 128;      // (+ one spare tile: pixels past the end)
+    const size_t ddt = (size_t)(pl.NI * HP * WP + 8) * 128;
+    return 2 * eh + ddt + (size_t)pl.PB + (size_t)(3 * d.ic * 64) + 512 + 2 * (size_t)pl.WB + 2048;
+}
+
+template <int K, int ACT, int CT, int RT>
+__device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan& pl, const float* __restrict__ x,
+                                            const u8* __restrict__ blob, const float* __restrict__ dZ,
+                                            const float* __restrict__ Dt, const float* __restrict__ gate,
+                                            const float* __restrict__ dpooled, float* __restrict__ dxp,
+                                            float* __restrict__ part, u8* lds, int ig, const FxSlice sl, int si) {
+    constexpr int KS = (CT + 1) / 2, PAD = K / 2, RS = 64 * KS + 32, PB = 96 * RS + 256, WBK = K * K * 128, WRB = 3 * CT * 16 * 64;
+    constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16), NVR = (WRB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
+    constexpr int NR = 2 * RT;                       // rounds of the dd loader: 128 RT pixels x 8 quads / 512 threads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, cq = tid & 7;
+    const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M;
+    const int HP = H + 2 * PAD, WP = (W + 2 * PAD) | 1;
+    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW, ntiles = (NPX + 15) >> 4;
+    const int g = sl.g, mcp = d.g[g].mcp, goff = d.g[g].off, nch = sl.nch;
+    const bool has_se = d.g[g].se > 0;
+    const float inv_hw = 1.f / (float)HW;
+    const int PADM = pl.KMAX / 2;
+    const int nt16a = ((pl.NI * HW + 15) / 16) * 16;
+    const size_t eh_b = (size_t)(nt16a + 16) * 128;
+    const size_t dd_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
+    float* EH[2] = {reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds + eh_b)};
+    float* DD = reinterpret_cast<float*>(lds + 2 * eh_b);
+    u8* Pb = lds + 2 * eh_b + dd_b;
+    u8* Wr = Pb + pl.PB;
+    f32x4* C2 = reinterpret_cast<f32x4*>(Wr + WRB);
+    u8* Wb[2] = {Wr + WRB + 512, Wr + WRB + 512 + pl.WB};
+    float* St = reinterpret_cast<float*>(Wr + WRB + 512 + 2 * pl.WB);
+
+    int slot[RT], prw[RT];                           // (compact tile: the pixel's own index; tiles past the end: the spare tile)
+    bool pv[RT];
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        prw[pt] = 16 * (wave + 8 * pt) + n;
+        pv[pt] = prw[pt] < NPX;
+        slot[pt] = prw[pt] < nt16a ? prw[pt] : nt16a + n;
+    }
+    FxX<KS, RT> X;
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        const float* __restrict__ xp = x + ((size_t)img0 * HW + prw[pt]) * ic + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool ok = pv[pt] && 32 * ks + 8 * q < ic;
+            const f32x4 a = ok ? ld4(xp + 32 * ks) : zero4(), b = ok ? ld4(xp + 32 * ks + 4) : zero4();
+            fx_split8(a, b, X.h[pt][ks], X.m[pt][ks], X.l[pt][ks]);
+        }
+    }
+    // the stencil item of this thread
+    FxItem it;
+    {
+        const int k8 = lane >> 3, j = wave * 8 + k8;
+        const int SCN = (W + 3) >> 2, per_img = SCN * H;
+        const int img = j / per_img, r = j - img * per_img, sc = r / H, oh = r - sc * H, ow0 = 4 * sc;
+        it.npx = (j < nimg * per_img) ? (W - ow0 < 4 ? W - ow0 : 4) : 0;
+        it.toff = ((img * HP + oh) * WP + ow0) * 32 + 4 * (lane & 7);
+        it.eoff = ((img * H + oh) * W + ow0) * 32 + 4 * (lane & 7);
+    }
+    // the dd loader's elements of this thread: pixel e >> 3 of the group, channel quad cq
+    int lslot[NR];
+    unsigned lpix[NR];
+    int limg[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int pix = (tid + r * FX_THREADS) >> 3;
+        const int img = pix / HW, rr = pix - img * HW, h = rr / W, w = rr - h * W;
+        lslot[r] = pix < NPX ? ((img * HP + h + PAD) * WP + w + PAD) * 32 + 4 * cq : -1;
+        lpix[r] = (unsigned)pix;
+        limg[r] = img;
+    }
+    for (size_t i = (size_t)tid * 16; i < dd_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + 2 * eh_b + i) = u32x4{0, 0, 0, 0};
+    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    {
+        FxCopy<NVP> cp;
+        FxCopy<1> cw, cc;
+        cp.load(bl0, PB);
+        cw.load(bl0 + pl.PB, WBK);
+        cc.load(bl0 + pl.PB + pl.WB, 512);
+        cp.store(Pb, PB);
+        cw.store(Wb[0], WBK);
+        cc.store(reinterpret_cast<u8*>(C2), 512);
+    }
+    f32x4 dx[CT][RT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < RT; ++pt) dx[ct][pt] = zero4();
+    __syncthreads();
+
+    const size_t pixbase = (size_t)img0 * HW;
+    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+    for (int i = 0; i <= nch; ++i) {
+        const int c0 = sl.c0 + 32 * i;
+        // ---- phase A: dd of chunk i -> LDS, ehat of chunk i (MFMA), dx += dE(i - 1) (rstd . W1)(i - 1)  (MFMA)
+        f32x4 dz[NR], dv[NR];
+        const bool chok = c0 + 4 * cq < mcp;
+        if (i < nch) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const bool ok = lslot[r] >= 0 && chok;
+                const size_t a = (pixbase + lpix[r]) * M + goff + c0 + 4 * cq;
+                dz[r] = ok ? ld4_nt(dZ + a) : zero4();
+                dv[r] = ok ? ld4_nt(Dt + a) : zero4();
+            }
+        }
+        if (i > 0) {
+            fx_stat_emit(St, prow, c0 - 32, mcp);
+            const float* eh = EH[(i - 1) & 1];
+            bf16x8 bh[RT], bm[RT], bl[RT];
+#pragma unroll
+            for (int pt = 0; pt < RT; ++pt) {
+                const float* bp = eh + slot[pt] * 32 + 8 * q;
+                fx_split8(ld4(bp), ld4(bp + 4), bh[pt], bm[pt], bl[pt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int row = 16 * ct + n;
+                const u8* ap = Wr + row * 64 + ((q ^ fx_swz(row)) * 16);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + CT * 16 * 64);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * CT * 16 * 64);
+#pragma unroll
+                for (int pt = 0; pt < RT; ++pt) {
+                    FX_MFMA6(dx[ct][pt], ah, am, al, bh[pt], bm[pt], bl[pt])
+                }
+            }
+        }
+        if (i == nch) break;
+        fx_expand<KS, RT, 2>(Pb, X, EH[i & 1], slot, pv, ntiles);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (lslot[r] >= 0) {
+                f32x4 v = zero4();
+                if (chok) {
+                    f32x4 g4 = zero4(), dp4 = zero4();
+                    if (has_se) {
+                        const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
+                        g4 = ld4(gate + o);
+                        dp4 = ld4(dpooled + o) * splat4(inv_hw);
+                    }
+                    v = fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
+                }
+                st4(DD + lslot[r], v);
+            }
+        }
+        __syncthreads();
+        // ---- phase B: stencil of chunk i (dE overwrites ehat in place); the next chunk's blob pieces come in meanwhile
+        FxCopy<NVP> cp;
+        FxCopy<NVR> cr;
+        FxCopy<1> cw, cc;
+        const bool nx = i + 1 < nch;
+        const u8* bi = bl0 + (size_t)i * pl.BLOB;
+        cr.load(bi + pl.PB + pl.WB + 512, WRB);
+        if (nx) {
+            cp.load(bi + pl.BLOB, PB);
+            cw.load(bi + pl.BLOB + pl.PB, WBK);
+            cc.load(bi + pl.BLOB + pl.PB + pl.WB, 512);
+        }
+        fx_bwd_stencil<K, ACT>(DD, reinterpret_cast<const float*>(Wb[i & 1]), EH[i & 1], it, WP, St);
+        cr.store(Wr, WRB);
+        if (nx) {
+            cp.store(Pb, PB);
+            cw.store(Wb[(i + 1) & 1], WBK);
+            cc.store(reinterpret_cast<u8*>(C2), 512);
+        }
+        __syncthreads();
+    }
+    // dx partial of this slice
+    float* __restrict__ dst = dxp + (size_t)si * d.N * HW * ic;
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        if (pv[pt]) {
+            float* __restrict__ o = dst + (pixbase + prw[pt]) * ic + 4 * q;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) st4(o + 16 * ct, dx[ct][pt]);
+        }
+    }
+}
+
+// ---- backward, stored-ehat mode: the forward left ehat = BN1(x W1^T) in the cell's E buffer (fx_expand, eg); no recompute, no
+// x planes: the workgroup's persistent state is the dx accumulators only.
+//   phase A(i): dd(i) = BN2-backward(dZ, D) -> LDS image tile;  dx += dE(i-1) (rstd . W1)(i-1)   (MFMA; A = Wr planes, B = dE tile)
+//   phase B(i): stencil (flipped taps) on dd(i), * act'(ehat) (ehat: 4 x 16 B per thread from global, requested before the taps),
+//               dE(i) -> LDS, t1 / t2 partial sums;  Wr(i), cst2(i+1), taps(i+1) arrive meanwhile
+static size_t fx_bwde_lds(const TfnasCellDesc& d, const FxPlan& pl) {
+    const int PAD = pl.KMAX / 2, HP = d.H + 2 * PAD, WP = (d.W + 2 * PAD) | 1;
+    const size_t de = (size_t)(((pl.NI * d.H * d.W + 15) / 16) * 16) * 128;
+    const size_t ddt = (size_t)(pl.NI * HP * WP + 8) * 128;
+    return de + ddt + (size_t)(3 * d.ic * 64) + 512 + 2 * (size_t)pl.WB + 2048;
+}
+
+template <int K, int ACT, int CT, int RT>
+__device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPlan& pl, const u8* __restrict__ blob,
+                                             const float* __restrict__ Eh, const float* __restrict__ dZ,
+                                             const float* __restrict__ Dt, const float* __restrict__ gate,
+                                             const float* __restrict__ dpooled, float* __restrict__ dxp,
+                                             float* __restrict__ part, u8* lds, int ig, const FxSlice sl, int si) {
+    constexpr int PAD = K / 2, WBK = K * K * 128, WRB = 3 * CT * 16 * 64;
+    constexpr int NVR = (WRB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
+    constexpr int NR = 2 * RT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, cq = tid & 7;
+    const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M;
+    const int HP = H + 2 * PAD, WP = (W + 2 * PAD) | 1;
+    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW, ntiles = (NPX + 15) >> 4;
+    const int g = sl.g, mcp = d.g[g].mcp, goff = d.g[g].off, nch = sl.nch;
+    const bool has_se = d.g[g].se > 0;
+    const float inv_hw = 1.f / (float)HW;
+    const int PADM = pl.KMAX / 2;
+    const size_t de_b = (size_t)(((pl.NI * HW + 15) / 16) * 16) * 128;
+    const size_t dd_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
+    float* DE = reinterpret_cast<float*>(lds);
+    float* DD = reinterpret_cast<float*>(lds + de_b);
+    u8* Wr = lds + de_b + dd_b;
+    f32x4* C2 = reinterpret_cast<f32x4*>(Wr + WRB);
+    u8* Wb[2] = {Wr + WRB + 512, Wr + WRB + 512 + pl.WB};
+    float* St = reinterpret_cast<float*>(Wr + WRB + 512 + 2 * pl.WB);
+
+    int prow_[RT];
+    bool pv[RT];
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        prow_[pt] = 16 * (wave + 8 * pt) + n;
+        pv[pt] = prow_[pt] < NPX;
+    }
+    FxItem it;
+    size_t eaddr;                                    // the item's first pixel in the [pixels][M] tensors (+ group, + quad)
+    {
+        const int k8 = lane >> 3, j = wave * 8 + k8;
+        const int SCN = (W + 3) >> 2, per_img = SCN * H;
+        const int img = j / per_img, r = j - img * per_img, sc = r / H, oh = r - sc * H, ow0 = 4 * sc;
+        const bool live = j < nimg * per_img;
+        it.npx = live ? (W - ow0 < 4 ? W - ow0 : 4) : 0;
+        it.toff = ((img * HP + oh) * WP + ow0) * 32 + 4 * (lane & 7);
+        it.eoff = ((img * H + oh) * W + ow0) * 32 + 4 * (lane & 7);
+        eaddr = live ? ((size_t)img0 * HW + (size_t)(img * H + oh) * W + ow0) * M + goff + 4 * (lane & 7) : (size_t)goff;
+    }
+    int lslot[NR];
+    unsigned lpix[NR];
+    int limg[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int pix = (tid + r * FX_THREADS) >> 3;
+        const int pc = pix < NPX ? pix : NPX - 1;
+        const int img = pc / HW, rr = pc - img * HW, h = rr / W, w = rr - h * W;
+        lslot[r] = pix < NPX ? ((img * HP + h + PAD) * WP + w + PAD) * 32 + 4 * cq : -1;
+        lpix[r] = (unsigned)pc;
+        limg[r] = img;
+    }
+    for (size_t i = (size_t)tid * 16; i < dd_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + de_b + i) = u32x4{0, 0, 0, 0};
+    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    {
+        FxCopy<1> cw, cc;
+        cw.load(bl0 + pl.PB, WBK);
+        cc.load(bl0 + pl.PB + pl.WB, 512);
+        cw.store(Wb[0], WBK);
+        cc.store(reinterpret_cast<u8*>(C2), 512);
+    }
+    f32x4 dx[CT][RT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < RT; ++pt) dx[ct][pt] = zero4();
+    __syncthreads();
+
+    const size_t pixbase = (size_t)img0 * HW;
+    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+    for (int i = 0; i <= nch; ++i) {
+        const int c0 = sl.c0 + 32 * i;
+        const bool chok = c0 + 4 * cq < mcp;
+        // ---- phase A
+        f32x4 dz[NR], dv[NR];
+        if (i < nch) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const size_t a = (pixbase + lpix[r]) * M + goff + c0 + 4 * cq;       // (in-bounds for every lane: clamped pixel)
+                dz[r] = ld4_nt(dZ + a);
+                dv[r] = ld4_nt(Dt + a);
+            }
+        }
+        if (i > 0) {
+            fx_stat_emit(St, prow, c0 - 32, mcp);
+            bf16x8 bh[RT], bm[RT], bl[RT];
+#pragma unroll
+            for (int pt = 0; pt < RT; ++pt) {
+                const float* bp = DE + prow_[pt] * 32 + 8 * q;
+                fx_split8(ld4(bp), ld4(bp + 4), bh[pt], bm[pt], bl[pt]);
+            }
+#pragma unroll
+            for (int ct0 = 0; ct0 < CT; ct0 += 2) {
+                bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = 16 * (ct0 + u < CT ? ct0 + u : ct0) + n;
+                    const u8* ap = Wr + row * 64 + ((q ^ fx_swz(row)) * 16);
+                    ah[u] = *reinterpret_cast<const bf16x8*>(ap);
+                    am[u] = *reinterpret_cast<const bf16x8*>(ap + CT * 16 * 64);
+                    al[u] = *reinterpret_cast<const bf16x8*>(ap + 2 * CT * 16 * 64);
+                }
+#define FX_GTERM(A_, B_)                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int pt = 0; pt < RT; ++pt) {                \
+        if (ct0 + u < CT)                                                                                            \
+            dx[ct0 + u < CT ? ct0 + u : ct0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+                A_[u], B_[pt], dx[ct0 + u < CT ? ct0 + u : ct0][pt], 0, 0, 0);                                       \
+    }
+                FX_GTERM(al, bh) FX_GTERM(am, bm) FX_GTERM(ah, bl) FX_GTERM(am, bh) FX_GTERM(ah, bm) FX_GTERM(ah, bh)
+#undef FX_GTERM
+            }
+        }
+        if (i == nch) break;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (lslot[r] >= 0) {
+                f32x4 g4 = zero4(), dp4 = zero4();
+                if (has_se) {
+                    const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
+                    g4 = ld4(gate + o);
+                    dp4 = ld4(dpooled + o) * splat4(inv_hw);
+                }
+                f32x4 v = fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
+                if (!chok) v = zero4();
+                st4(DD + lslot[r], v);
+            }
+        }
+        __syncthreads();
+        // ---- phase B
+        f32x4 ev[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ev[jj] = ld4_nt(Eh + eaddr + c0 + (size_t)(jj < it.npx ? jj : 0) * M);
+        FxCopy<NVR> cr;
+        FxCopy<1> cw, cc;
+        const bool nx = i + 1 < nch;
+        const u8* bi = bl0 + (size_t)i * pl.BLOB, *bn = bl0 + (size_t)(nx ? i + 1 : i) * pl.BLOB;
+        cr.load(bi + pl.PB + pl.WB + 512, WRB);
+        cw.load(bn + pl.PB, WBK);
+        cc.load(bn + pl.PB + pl.WB, 512);
+        {
+            const float* taps = reinterpret_cast<const float*>(Wb[i & 1]);
+            f32x4 t1 = zero4(), t2 = zero4();
+            if (it.npx > 0) {
+                const float* base = DD + it.toff;
+                f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll 1
+                for (int ky = 0; ky < K; ++ky) {
+                    const float* rowp = base + ky * WP * 32;
+                    const float* wp = taps + (K * K - 1 - ky * K) * 32 + 4 * cq;      // flipped taps
+                    f32x4 win[K + 3];
+#pragma unroll
+                    for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const f32x4 wv = ld4(wp - kx * 32);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (jj < it.npx) {
+                        f32x4 de = zero4();
+                        if (chok) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                de[r] = acc[jj][r] * act_d<ACT>(ev[jj][r]);
+                                t1[r] += de[r];
+                                t2[r] += de[r] * ev[jj][r];
+                            }
+                        }
+                        st4(DE + it.eoff + jj * 32, de);
+                    }
+                }
+            }
+            fx_stat_park(t1, t2, St);
+        }
+        cr.store(Wr, WRB);
+        if (nx) {
+            cw.store(Wb[(i + 1) & 1], WBK);
+            cc.store(reinterpret_cast<u8*>(C2), 512);
+        }
+        __syncthreads();
+    }
+    float* __restrict__ dst = dxp + (size_t)si * d.N * HW * ic;
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+        if (pv[pt]) {
+            float* __restrict__ o = dst + (pixbase + prow_[pt]) * ic + 4 * q;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) st4(o + 16 * ct, dx[ct][pt]);
+        }
+    }
+}
+
+template <int ACT, int CT, int RT>
+__global__ __launch_bounds__(FX_THREADS) void k_fx_bwde(TfnasCellDesc d, FxPlan pl, const u8* __restrict__ blob,
+                                                        const float* __restrict__ Eh, const float* __restrict__ dZ,
+                                                        const float* __restrict__ Dt, const float* __restrict__ gate,
+                                                        const float* __restrict__ dpooled, float* __restrict__ dxp,
+                                                        float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) u8 fx_lds[];
+    const int si = blockIdx.x / pl.nig, ig = blockIdx.x - si * pl.nig;
+    const FxSlice sl = pl.sl[si];
+    if (d.g[sl.g].k == 3) fx_bwde_body<3, ACT, CT, RT>(d, pl, blob, Eh, dZ, Dt, gate, dpooled, dxp, part, fx_lds, ig, sl, si);
+    else fx_bwde_body<5, ACT, CT, RT>(d, pl, blob, Eh, dZ, Dt, gate, dpooled, dxp, part, fx_lds, ig, sl, si);
+}
+
+template <int ACT, int CT, int RT>
+__global__ __launch_bounds__(FX_THREADS) void k_fx_bwd(TfnasCellDesc d, FxPlan pl, const float* __restrict__ x,
+                                                       const u8* __restrict__ blob, const float* __restrict__ dZ,
+                                                       const float* __restrict__ Dt, const float* __restrict__ gate,
+                                                       const float* __restrict__ dpooled, float* __restrict__ dxp,
+                                                       float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) u8 fx_lds[];
+    const int si = blockIdx.x / pl.nig, ig = blockIdx.x - si * pl.nig;
+    const FxSlice sl = pl.sl[si];
+    if (d.g[sl.g].k == 3) fx_bwd_body<3, ACT, CT, RT>(d, pl, x, blob, dZ, Dt, gate, dpooled, dxp, part, fx_lds, ig, sl, si);
+    else fx_bwd_body<5, ACT, CT, RT>(d, pl, x, blob, dZ, Dt, gate, dpooled, dxp, part, fx_lds, ig, sl, si);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- BN1 statistics
+// sum_p E and sum_p E^2 per mid channel from x alone (efree_kernels.hip has the algebra and the ic <= 40 kernels): the centred
+// Gram matrix C = sum_p (x - xbar)(x - xbar)^T on the fp32 matrix cores for ic up to 192 -- wave w owns the column tiles
+// j = w, w + 4, ..., all row tiles -- and the quadratic forms w_m^T C w_m in double.
+template <int CT>
+__global__ __launch_bounds__(256) void k_fx_gram(const float* __restrict__ x, int P, int ic, int rps,
+                                                 const double* __restrict__ xsum, float* __restrict__ part) {
+    constexpr int JT = (CT + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * rps, r1 = min(P, r0 + rps);
+    float mu[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) mu[t] = (float)(xsum[16 * t + n] / (double)P);
+    f32x4 acc[CT][JT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[i][j] = zero4();
+    for (int p = r0; p < r1; p += 4) {
+        const int row = p + q;
+        float a[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) a[t] = row < r1 ? x[(size_t)row * ic + 16 * t + n] - mu[t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int jt = wave + 4 * j;
+            if (jt < CT) {
+                // (a[jt] with a run-time index would go through scratch: select it)
+                float bj = 0.f;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) bj = t == jt ? a[t] : bj;
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bj, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // acc[i][j][r] of lane (n, q) = C[16 i + 4 q + r][16 (wave + 4 j) + n]
+    float* __restrict__ out = part + (size_t)blockIdx.x * ic * ic;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int jt = wave + 4 * j;
+        if (jt < CT) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(16 * i + 4 * q + r) * ic + 16 * jt + n] = acc[i][j][r];
+        }
+    }
+}
+
+// stats1[2 col] = sum_p E, [2 col + 1] = sum_p E^2 for 32 channels per workgroup: thread = (channel, eighth of the rows of C)
+__global__ __launch_bounds__(256) void k_fx_stats1(TfnasCellDesc d, const double* __restrict__ xsum, const double* __restrict__ C,
+                                                   double* __restrict__ stats1) {
+    __shared__ double red[2][8][32];
+    const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5, ic = d.ic;
+    const int col = blockIdx.x * 32 + cl;
+    int g = 0;
+    for (; g < d.G - 1; ++g)
+        if (col < d.g[g + 1].off) break;
+    const int m = col - d.g[g].off;
+    const bool ok = col < d.M && m >= 0 && m < d.g[g].mc;
+    double s = 0.0, qf = 0.0;
+    if (ok) {
+        const float* __restrict__ w = d.g[g].w_expand + (size_t)m * ic;
+        const int per = (ic + 7) / 8, ca = part * per, cb = min(ic, ca + per);
+        for (int c = ca; c < cb; ++c) {
+            const double* __restrict__ row = C + (size_t)c * ic;
+            double t0 = 0.0, t1 = 0.0;
+            for (int c2 = 0; c2 < ic; c2 += 2) {
+                t0 += row[c2] * (double)w[c2];
+                t1 += row[c2 + 1] * (double)w[c2 + 1];
+            }
+            qf += (double)w[c] * (t0 + t1);
+            s += (double)w[c] * xsum[c];
+        }
+    }
+    red[0][part][cl] = s;
+    red[1][part][cl] = qf;
+    __syncthreads();
+    if (tid < 32 && col < d.M) {
+        double ss = 0.0, qq = 0.0;
+        for (int p = 0; p < 8; ++p) {
+            ss += red[0][p][cl];
+            qq += red[1][p][cl];
+        }
+        const double P = (double)d.N * d.H * d.W;
+        if (ok) qq += ss * ss / P;                                   // sum E^2 = centred sum of squares + P mean^2
+        stats1[2 * (size_t)col + 0] = ok ? ss : 0.0;
+        stats1[2 * (size_t)col + 1] = ok ? qq : 0.0;
+    }
+}
+
+// scratch (`part`): partial rows from the bottom, the double results xsum[ic] | C[ic * ic] in the top
+int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, float* part, hipStream_t s) {
+    const int P = d.N * d.H * d.W, ic = d.ic, ne = ic * ic;
+    int nb = 256;
+    while (nb > 1 && (size_t)nb * ne + 2 * (size_t)(ne + ic + 4) + 64 > TFNAS_PART_FLOATS) nb >>= 1;
+    int rps = cdiv(P, nb);
+    rps = (rps + 3) & ~3;
+    if (rps < 16) rps = 16;
+    nb = cdiv(P, rps);
+    double* xsum = reinterpret_cast<double*>(part + TFNAS_PART_FLOATS) - (ne + ic + 2);
+    xsum = reinterpret_cast<double*>((uintptr_t)xsum & ~(uintptr_t)15);
+    double* Cm = xsum + ic;
+    int rc = launch_x_colsum(x, P, ic, rps, nb, part, s);
+    if (rc) return rc;
+    rc = launch_reduce_rows(part, nb, ic, (size_t)ic, xsum, nullptr, s);
+    if (rc) return rc;
+    {
+        ProfScope _prof(TK_EXPAND_FWD, s);
+        const int CT = ic / 16;
+        switch (CT) {
+#define FX_GRAM(N_) case N_: hipLaunchKernelGGL(k_fx_gram<N_>, dim3(nb), dim3(256), 0, s, x, P, ic, rps, xsum, part); break;
+            FX_GRAM(4) FX_GRAM(5) FX_GRAM(6) FX_GRAM(7) FX_GRAM(8) FX_GRAM(9) FX_GRAM(10) FX_GRAM(11) FX_GRAM(12)
+#undef FX_GRAM
+            default: return TFNAS_EINVAL;
+        }
+    }
+    rc = launch_reduce_rows(part, nb, ne, (size_t)ne, Cm, nullptr, s);
+    if (rc) return rc;
+    ProfScope _prof(TK_SMALL, s);
+    hipLaunchKernelGGL(k_fx_stats1, dim3(cdiv(d.M, 32)), dim3(256), 0, s, d, xsum, Cm, stats1);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- launchers
+static bool fx_attr_done(const void* fn, size_t shm) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;
+}
+
+int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* E, float* D, double* stats2,
+                  float* part, hipStream_t s) {
+    FxPlan pl;
+    if (!fx_plan(d, pl, false)) return TFNAS_EINVAL;
+    const size_t rows = ((size_t)pl.nig * 2 * d.M + 63) & ~(size_t)63;
+    u8* blob = reinterpret_cast<u8*>(part + rows);
+    {
+        ProfScope _prof(TK_SMALL, s);
+        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks), dim3(256), 0, s, d, pl, stats1, (const double*)nullptr,
+                           (const double*)nullptr, blob);
+    }
+    const size_t shm = fx_fwd_lds(d, pl);
+    const dim3 grid(pl.nig * pl.nslices);
+    {
+        ProfScope _prof(TK_DW_FWD, s, d.G > 2);
+#define FX_FWD(A_, KS_, RT_)                                                                                        \
+    {                                                                                                               \
+        static bool attr = fx_attr_done((const void*)k_fx_fwd<A_, KS_, RT_>, 160 * 1024);                           \
+        if (!attr) return TFNAS_EINVAL;                                                                             \
+        hipLaunchKernelGGL((k_fx_fwd<A_, KS_, RT_>), grid, dim3(FX_THREADS), shm, s, d, pl, x, blob, D, part, E);   \
+    }
+#define FX_FWD_A(KS_, RT_)                                                       \
+    {                                                                            \
+        if (d.act == TFNAS_ACT_RELU) FX_FWD(0, KS_, RT_) else FX_FWD(1, KS_, RT_) \
+    }
+        const int key = pl.KS * 10 + pl.RT;
+        switch (key) {
+            case 21: FX_FWD_A(2, 1) break;
+            case 22: FX_FWD_A(2, 2) break;
+            case 31: FX_FWD_A(3, 1) break;
+            case 32: FX_FWD_A(3, 2) break;
+            case 41: FX_FWD_A(4, 1) break;
+            case 42: FX_FWD_A(4, 2) break;
+            case 51: FX_FWD_A(5, 1) break;
+            case 61: FX_FWD_A(6, 1) break;
+            default: return TFNAS_EINVAL;
+        }
+#undef FX_FWD_A
+#undef FX_FWD
+    }
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return launch_reduce_rows(part, pl.nig, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
+}
+
+// scratch layout of the backward: dxp [nsl + 1][P][ic] floats | blobs (256-byte aligned) -- in `scratch` (the cell's dEh buffer,
+// which the fused route never uses for dE) when it is large enough, else the blobs go behind the statistics rows in `part`
+static bool fx_bwd_layout(const TfnasCellDesc& d, const FxPlan& pl, size_t scratch_floats, size_t& blob_off_scratch,
+                          size_t& blob_off_part) {
+    const size_t P = (size_t)d.N * d.H * d.W;
+    const size_t dxp = (((size_t)(pl.nslices + 1) * P * d.ic) + 63) & ~(size_t)63;
+    const size_t blobs = ((size_t)pl.nchunks * pl.BLOB + 3) / 4;
+    if (dxp > scratch_floats) return false;
+    blob_off_scratch = blob_off_part = ~(size_t)0;
+    if (dxp + blobs <= scratch_floats) {
+        blob_off_scratch = dxp;
+        return true;
+    }
+    const size_t rows = ((size_t)pl.nig * 2 * d.M + 63) & ~(size_t)63;
+    if (rows + blobs + 256 > TFNAS_PART_FLOATS) return false;
+    blob_off_part = rows;
+    return true;
+}
+
+// TFNAS_FX = 1 | 0: the fused per-image route for the frozen-weight launches it covers / never
+#ifndef TFNAS_FX_DEFAULT
+#define TFNAS_FX_DEFAULT 0
+#endif
+static bool fx_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("TFNAS_FX");
+        return e ? e[0] != '0' : TFNAS_FX_DEFAULT != 0;
+    }();
+    return on;
+}
+
+bool fx_supported(const TfnasCellDesc& d) {
+    FxPlan pl;
+    if (!fx_enabled() || !fx_plan(d, pl, false)) return false;
+    if (fx_fwd_lds(d, pl) > 160 * 1024) return false;
+    // forward scratch in `part`: statistics partial rows | blobs | (top) xsum, C
+    const size_t rows = (((size_t)pl.nig * 2 * d.M) + 63) & ~(size_t)63, blobs = ((size_t)pl.nchunks * pl.BLOB + 3) / 4;
+    const size_t top = 2 * (size_t)(d.ic * d.ic + d.ic + 4) + 64;
+    if (rows + blobs + top + 256 > TFNAS_PART_FLOATS) return false;
+    FxPlan pb;
+    if (!fx_plan(d, pb, true)) return false;
+    if (fx_bwd_lds(d, pb) > 160 * 1024 || fx_bwde_lds(d, pb) > 160 * 1024) return false;
+    size_t a, b;
+    return fx_bwd_layout(d, pb, (size_t)d.N * d.H * d.W * d.M, a, b);
+}
+
+int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const double* stats1, const double* stats2,
+                  const double* red2, const float* dZ, const float* D, const float* gate, const float* dpooled, float* scratch,
+                  size_t scratch_floats, double* red1, float* cb1, float* part, int* nsl, hipStream_t s) {
+    FxPlan pl;
+    if (!fx_plan(d, pl, true)) return TFNAS_EINVAL;
+    size_t bo_s, bo_p;
+    if (!fx_bwd_layout(d, pl, scratch_floats, bo_s, bo_p)) return TFNAS_ERANGE;
+    u8* blob = reinterpret_cast<u8*>(bo_s != ~(size_t)0 ? scratch + bo_s : part + bo_p);
+    {
+        ProfScope _prof(TK_SMALL, s);
+        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks), dim3(256), 0, s, d, pl, stats1, stats2, red2, blob);
+    }
+    const size_t shm = Eh ? fx_bwde_lds(d, pl) : fx_bwd_lds(d, pl);
+    const dim3 grid(pl.nig * pl.nslices);
+    {
+        ProfScope _prof(TK_DW_BWD_DATA, s, d.G > 2);
+#define FX_BWD(A_, CT_, RT_)                                                                                         \
+    {                                                                                                                \
+        static bool attr = fx_attr_done((const void*)k_fx_bwd<A_, CT_, RT_>, 160 * 1024) &&                          \
+                           fx_attr_done((const void*)k_fx_bwde<A_, CT_, RT_>, 160 * 1024);                           \
+        if (!attr) return TFNAS_EINVAL;                                                                              \
+        if (Eh)                                                                                                      \
+            hipLaunchKernelGGL((k_fx_bwde<A_, CT_, RT_>), grid, dim3(FX_THREADS), shm, s, d, pl, blob, Eh, dZ, D,    \
+                               gate, dpooled, scratch, part);                                                        \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_fx_bwd<A_, CT_, RT_>), grid, dim3(FX_THREADS), shm, s, d, pl, x, blob, dZ, D,      \
+                               gate, dpooled, scratch, part);                                                        \
+    }
+#define FX_BWD_A(CT_, RT_)                                                       \
+    {                                                                            \
+        if (d.act == TFNAS_ACT_RELU) FX_BWD(0, CT_, RT_) else FX_BWD(1, CT_, RT_) \
+    }
+        const int key = (d.ic / 16) * 10 + pl.RT;
+        switch (key) {
+            case 41: FX_BWD_A(4, 1) break;
+            case 42: FX_BWD_A(4, 2) break;
+            case 51: FX_BWD_A(5, 1) break;
+            case 52: FX_BWD_A(5, 2) break;
+            case 61: FX_BWD_A(6, 1) break;
+            case 62: FX_BWD_A(6, 2) break;
+            case 71: FX_BWD_A(7, 1) break;
+            case 72: FX_BWD_A(7, 2) break;
+            case 81: FX_BWD_A(8, 1) break;
+            case 82: FX_BWD_A(8, 2) break;
+            case 91: FX_BWD_A(9, 1) break;
+            case 101: FX_BWD_A(10, 1) break;
+            case 111: FX_BWD_A(11, 1) break;
+            case 121: FX_BWD_A(12, 1) break;
+            default: return TFNAS_EINVAL;
+        }
+#undef FX_BWD_A
+#undef FX_BWD
+    }
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    *nsl = pl.nslices;
+    return launch_reduce_bn1(d, part, pl.nig, stats1, red1, cb1, s);
+}

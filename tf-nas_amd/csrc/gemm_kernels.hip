@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
                                                       const float* __restrict__ wmix, float* __restrict__ dx,
                                                       float* __restrict__ dxp, int nsplit,
                                                       const float* __restrict__ add_src,
-                                                      const float* __restrict__ add_scale) {
+                                                      const float* __restrict__ add_scale, int xonly_slot = -1) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
     const int n0 = blockIdx.y * T::BN;
@@ -736,12 +736,16 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
     int mchunks = 0;
     for (int g = 0; g < d.G; ++g) mchunks += (d.g[g].mcp + 15) >> 4;
     const int nchunks_all = mchunks + ((ic + 15) >> 4);      // mid-channel chunks, then the x / -G chunks
-    const int per = (nchunks_all + nsplit - 1) / nsplit;
-    const int cbeg = zs * per;
+    // xonly_slot >= 0 (fused per-image route, fx_kernels.hip: the dE (rstd . W) term already sits in dxp[0 .. xonly_slot) as
+    // partial sums): only the trailing x / -G chunks, written as one more partial tile dxp[xonly_slot]; k_dx_reduce adds them up
+    const bool xonly = xonly_slot >= 0;
+    const int per = xonly ? nchunks_all - mchunks : (nchunks_all + nsplit - 1) / nsplit;
+    const int cbeg = xonly ? mchunks : zs * per;
     const int nchunks = max(0, min(nchunks_all, cbeg + per) - cbeg);
-    float* __restrict__ dst = nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx;
-    const bool add_res = d.has_res && nsplit == 1;
-    const bool add_sink = add_src != nullptr && nsplit == 1;
+    float* __restrict__ dst = xonly ? dxp + (size_t)xonly_slot * P * ic : (nsplit > 1 ? dxp + (size_t)blockIdx.z * P * ic : dx);
+    const bool plain = nsplit == 1 && !xonly;
+    const bool add_res = d.has_res && plain;
+    const bool add_sink = add_src != nullptr && plain;
     const float sink_w = add_src ? add_scale[0] : 0.f;
     float sumw = 1.f;
     if (wmix) {
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(256, gemm_lb(NT, MM)) void k_expand_dgrad(TfnasCell
         emit_tile_rows<NT>(acc, lds, [&](int lrow, int lc, f32x4 v) {
             const int p = rt * 128 + lrow, c = n0 + lc;
             if (p < P && c < ic) {
-                if (nsplit == 1) v += ld4(gram + (size_t)ic * ic + c);
+                if (plain) v += ld4(gram + (size_t)ic * ic + c);
                 if (add_res) v += splat4(sumw) * ld4(dout + (size_t)p * d.oc + c);
                 if (add_sink) v = sink_add(v, sink_w, ld4(add_src + (size_t)p * ic + c));
                 st4(dst + (size_t)p * ic + c, v);
@@ -1336,6 +1340,31 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
         hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks, ng), dim3(256), 0, s, d, dxp, nsplit, gram, dout, wmix, dx,
                            add_src, add_scale);
     }
+    return (int)hipGetLastError();
+}
+
+// fused per-image route (fx_kernels.hip): dxp[0 .. nsl) hold the partial sums of dE (rstd . W1); this adds the BN1-backward
+// correction -x G (one more partial tile, MFMA) and sums everything (+ b, + residual, + sink gradient) into dx
+int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* cb1, const float* gram, const float* dout,
+                          const float* wmix, float* dx, float* dxp, int nsl, hipStream_t s, const float* add_src,
+                          const float* add_scale) {
+    {
+        ProfScope _prof(TK_EXPAND_DGRAD, s);
+        const int nt = pick_nt(d.ic, kNtSmall, 6);
+        const int tiles = cdiv(d.ic, 16 * nt);
+        const int mm = gemm_mode_dgrad(d);
+        dim3 grid(row_blocks(d.N * d.H * d.W, tiles, 1u << 30, gemm_slots(nt, mm), 4096), tiles, 1);
+        DISPATCH_MM_(mm, DISPATCH_NT(nt, {
+            hipLaunchKernelGGL((k_expand_dgrad<NT, MM>), grid, dim3(256), 0, s, d, (const float*)nullptr, x, cb1, gram, dout, wmix,
+                               dx, dxp, 1, add_src, add_scale, nsl);
+        }))
+    }
+    ProfScope _p2(TK_SMALL, s);
+    const size_t n4 = (size_t)d.N * d.H * d.W * d.ic / 4;
+    size_t blocks = cdiv64(n4, 256 * 2);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_dx_reduce, dim3((unsigned)blocks, 1), dim3(256), 0, s, d, dxp, nsl + 1, gram, dout, wmix, dx, add_src,
+                       add_scale);
     return (int)hipGetLastError();
 }
 

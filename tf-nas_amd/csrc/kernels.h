@@ -45,6 +45,9 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
                         const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s,
                         const float* add_src = nullptr, const float* add_scale = nullptr);
 int expand_dgrad_splits(const TfnasCellDesc& d);
+int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* cb1, const float* gram, const float* dout,
+                          const float* wmix, float* dx, float* dxp, int nsl, hipStream_t s, const float* add_src = nullptr,
+                          const float* add_scale = nullptr);
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s);
 
@@ -53,7 +56,21 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
 int launch_dw_fwd(const TfnasCellDesc& d, const float* E, const float* x, const double* stats1, float* D,
                   double* stats2, float* part, hipStream_t s);
 bool efree_supported(const TfnasCellDesc& d);
+static inline bool efree_ic_small(int ic) { return ic == 16 || ic == 24 || ic == 40; }   // (efree.h: the tile / ring E-free kernels)
 int launch_expand_stats_gram(const TfnasCellDesc& d, const float* x, double* stats1, float* part, hipStream_t s);
+int launch_x_colsum(const float* x, int P, int ic, int rps, int nb, float* part, hipStream_t s);
+// fx_kernels.hip: fused per-image route of the late cells (fx.h) -- E-free cells with 64 <= ic <= 192 and images <= 14 x 14
+bool fx_supported(const TfnasCellDesc& d);
+int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, float* part, hipStream_t s);
+// E != nullptr ("stored-ehat mode"): the forward also leaves ehat = BN1(x W1^T) in E and the backward reads it back instead of
+// recomputing it; E == nullptr: nothing is stored, the backward rebuilds ehat from x
+int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* E, float* D, double* stats2,
+                  float* part, hipStream_t s);
+// backward: the partial sums of dE (rstd . W1) into scratch[0 .. nsl * P * ic) (nsl returned), the BN1-backward sums into
+// red1 and the cb1 table; the caller finishes with launch_expand_gram + launch_expand_dgrad_x(scratch, nsl)
+int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const double* stats1, const double* stats2,
+                  const double* red2, const float* dZ, const float* D, const float* gate, const float* dpooled, float* scratch,
+                  size_t scratch_floats, double* red1, float* cb1, float* part, int* nsl, hipStream_t s);
 int launch_dw_bwd_data(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                        const float* D, const double* stats2,
                        const double* red2, const float* E, const float* x, const double* stats1, float* dEh,

@@ -96,6 +96,7 @@ _PROTOS = {
     'tfnas_arch_fwd': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, _P, _P, _P]),
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
+    'tfnas_fx_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_arch_project': (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),
@@ -129,7 +130,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)        # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if l.tfnas_abi_version() != 2:
+        if l.tfnas_abi_version() != 3:
             raise RuntimeError('tfnas_amd: ABI version mismatch')
         for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs, TfnasBnAffine)):
             if l.tfnas_sizeof(which) != C.sizeof(st):

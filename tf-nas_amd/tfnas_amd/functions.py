@@ -23,6 +23,8 @@ BN_EPS = 1e-5
 _EFREE_ENV = os.environ.get('TFNAS_EFREE', '1')
 EFREE = _EFREE_ENV != '0'
 EFREE_STRIDE1 = _EFREE_ENV == 'all'
+# (TFNAS_FX = 1 (default) | 0 is read by the library: frozen-weight launches of the cells at 14 x 14 / 7 x 7 through the fused
+#  per-image kernels, csrc/fx_kernels.hip / through the materialised route)
 
 
 def _stream(dev):
@@ -144,6 +146,8 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     _same_device(dev, list(params) + [wmix], 'a MixedOP weight / mix weight')
     # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
     # cells never materialise the expanded tensor -- the depthwise kernels recompute it from x
+    # (the late cells -- tfnas_fx_supported -- keep their E buffer: the fused per-image kernels leave ehat in it for the backward;
+    #  TFNAS_EFREE=all drops it there too and the backward recomputes)
     efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and not any(ctx.needs_input_grad[3:])
              and bool(_lib.lib().tfnas_efree_supported(C.byref(d))))
     E = None if efree else torch.empty(ws.E, device=dev, dtype=torch.float32)

@@ -40,6 +40,8 @@ for ci in want:
     P, Po = B * size * size, B * so * so
     x = torch.randn(B, ic, size, size, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     labels = (('soft', tuple(range(8))), ('samp5', (5,)))
+    if os.environ.get('CF_SOFT_ONLY') == '1':
+        labels = labels[:1]
     if os.environ.get('CF_SAMPLED_ONLY') == '1':
         labels = tuple(('samp%d' % int(i), (int(i),)) for i in os.environ.get('CF_IDX', '2,5').split(','))
     for label, idxs in labels:
