@@ -22,7 +22,8 @@ constexpr int FX_THREADS = 512;
 
 struct FxPlan {
     int KS;            // MFMA k-steps of 32 input channels: ceil(ic / 32)
-    int RT;            // 16-pixel tiles per wave (8 waves): 1 or 2
+    int RT;            // 16-pixel tiles per wave: backward (8 waves), 1 or 2
+    int RTF;           // ... forward (7 worker waves + 1 copier wave)
     int NI;            // images per workgroup
     int nig;           // image groups = ceil(N / NI)
     int RS;            // bytes per channel row of a bf16 plane in a blob (32 * KS * 2 + 32: conflict-free ds_read_b128)

@@ -25,6 +25,13 @@
 #include "prof.h"
 #include "fx.h"
 #include "gemm_x3.h"
+#include <type_traits>
+
+// timing-only ablation of the fused kernels (tools/r5_fxabl.sh): bit 0 no stencil taps, 1 no expand MFMAs, 2 no D / E stores,
+// 3 no blob copies, 4 no activation in the expand epilogue.  Never set in the product build.
+#ifndef FX_ABL
+#define FX_ABL 0
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------- plan
 static int fx_ks(int ic) { return (ic + 31) / 32; }
@@ -42,9 +49,10 @@ bool fx_plan(const TfnasCellDesc& d, FxPlan& pl, bool bwd) {
     if (NI > 4) NI = 4;
     if (NI > d.N) NI = d.N;
     const int ntiles = (NI * HW + 15) / 16, RT = (ntiles + 7) / 8;
-    if (RT * KS > 8) return false;                          // register budget of the x planes: 12 * RT * KS VGPRs
-    if (NI * ((d.Wo + 3) / 4) * d.Ho > 64) return false;    // one stencil item (4-pixel strip x channel quad) per thread
-    pl.KS = KS; pl.RT = RT; pl.NI = NI;
+    const int RTF = (ntiles + 6) / 7;                       // forward: 7 worker waves
+    if (RTF * KS > 8) return false;                         // register budget of the x planes: 12 * RT * KS VGPRs
+    if (NI * ((d.Wo + 3) / 4) * d.Ho > 56) return false;    // one stencil item (4-pixel strip x channel quad) per worker thread
+    pl.KS = KS; pl.RT = RT; pl.RTF = RTF; pl.NI = NI;
     pl.nig = (d.N + NI - 1) / NI;
     pl.RS = 64 * KS + 32;
     int kmax = 3;
@@ -117,7 +125,8 @@ __device__ __forceinline__ void fx_split3(float v, unsigned short& h, unsigned s
 __global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, const double* __restrict__ stats1,
                                                  const double* __restrict__ stats2, const double* __restrict__ red2,
                                                  unsigned char* __restrict__ blob) {
-    const int chunk = blockIdx.x, tid = threadIdx.x;
+    // grid = (chunks, 4): workgroup y packs channels 8 y .. 8 y + 7 of the chunk (126-216 workgroups alone left the chip idle: 21 us)
+    const int chunk = blockIdx.x, cy = blockIdx.y * 8, tid = threadIdx.x;
     int si = 0;
     for (; si < pl.nslices - 1; ++si)
         if (chunk < pl.sl[si + 1].chunk0) break;
@@ -126,15 +135,15 @@ __global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, con
     const int RS = pl.RS, KP = 32 * pl.KS;
     unsigned char* b = blob + (size_t)chunk * pl.BLOB;
     const float* __restrict__ w1 = d.g[g].w_expand;
-    __shared__ float2 cst[32];
-    if (tid < 32) {
+    __shared__ float2 cst[8];
+    if (tid < 8) {
         float2 c = make_float2(0.f, 0.f);
-        if (c0 + tid < mc) c = bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * d.H * d.W), d.eps);
+        if (c0 + cy + tid < mc) c = bn_consts(stats1 + 2 * (size_t)(off + c0 + cy + tid), 1.0 / ((double)d.N * d.H * d.W), d.eps);
         cst[tid] = c;
-        reinterpret_cast<float2*>(b + 96 * RS)[tid] = c;
+        reinterpret_cast<float2*>(b + 96 * RS)[cy + tid] = c;
     }
-    for (int e = tid; e < 32 * KP; e += 256) {
-        const int ch = e / KP, k = e - ch * KP;
+    for (int e = tid; e < 8 * KP; e += 256) {
+        const int ch = cy + e / KP, k = e % KP;
         const float v = (c0 + ch < mc && k < ic) ? w1[(size_t)(c0 + ch) * ic + k] : 0.f;
         unsigned short h, m, l;
         fx_split3(v, h, m, l);
@@ -144,29 +153,30 @@ __global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, con
         row[32 * RS] = l;
     }
     float* taps = reinterpret_cast<float*>(b + pl.PB);
-    for (int e = tid; e < KK * 32; e += 256) {
-        const int t = e >> 5, ch = e & 31;
-        taps[e] = (c0 + ch < mc) ? d.g[g].w_dw[(size_t)(c0 + ch) * KK + t] : 0.f;
+    for (int e = tid; e < KK * 8; e += 256) {
+        const int t = e >> 3, ch = cy + (e & 7);
+        taps[t * 32 + ch] = (c0 + ch < mc) ? d.g[g].w_dw[(size_t)(c0 + ch) * KK + t] : 0.f;
     }
     if (pl.XB) {
         f32x4* c2 = reinterpret_cast<f32x4*>(b + pl.PB + pl.WB);
-        if (tid < 32) {
+        if (tid < 8) {
             f32x4 t = zero4();
-            if (c0 + tid < mc) {
+            const int ch = cy + tid;
+            if (c0 + ch < mc) {
                 const double inv = 1.0 / ((double)d.N * d.Ho * d.Wo);
-                const float2 c = bn_consts(stats2 + 2 * (size_t)(off + c0 + tid), inv, d.eps);
+                const float2 c = bn_consts(stats2 + 2 * (size_t)(off + c0 + ch), inv, d.eps);
                 t.x = c.x;
                 t.y = c.y;
-                t.z = (float)(red2[2 * (size_t)(off + c0 + tid) + 0] * inv);
-                t.w = (float)(red2[2 * (size_t)(off + c0 + tid) + 1] * inv);
+                t.z = (float)(red2[2 * (size_t)(off + c0 + ch) + 0] * inv);
+                t.w = (float)(red2[2 * (size_t)(off + c0 + ch) + 1] * inv);
             }
-            c2[tid] = t;
+            c2[ch] = t;
         }
         __syncthreads();
         unsigned char* wr = b + pl.PB + pl.WB + 512;
-        for (int e = tid; e < 32 * ic; e += 256) {
-            const int ch = e / ic, c = e - ch * ic;          // (reads of W1 rows stay coalesced)
-            const float v = (c0 + ch < mc) ? cst[ch].y * w1[(size_t)(c0 + ch) * ic + c] : 0.f;
+        for (int e = tid; e < 8 * ic; e += 256) {
+            const int chl = e / ic, c = e - chl * ic, ch = cy + chl;      // (reads of W1 rows stay coalesced)
+            const float v = (c0 + ch < mc) ? cst[chl].y * w1[(size_t)(c0 + ch) * ic + c] : 0.f;
             unsigned short h, m, l;
             fx_split3(v, h, m, l);
             const int grp = (ch >> 3) ^ fx_swz(c);
@@ -231,7 +241,7 @@ struct FxCopy {
 //  instruction counts; tiles past the end of the workgroup's pixels multiply zero x planes instead)
 #define FX_TERM(A_, B_)                                                                                                  \
     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) _Pragma("unroll") for (int pt = 0; pt < RT; ++pt)                   \
-        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[ct], X.B_[pt][ks], acc[ct][pt], 0, 0, 0);
+        if (!(FX_ABL & 2)) acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[ct], X.B_[pt][ks], acc[ct][pt], 0, 0, 0);
 
 // e = BN1(x W1_chunk^T) for the wave's pixel tiles: A = W1 planes (LDS blob), B = x planes (registers).  Lane (n, q) of tile
 // (ct, pt) ends up with channels 16 ct + 4 q .. + 3 of pixel 16 (wave + 8 pt) + n; OUT = 0 / 1: act(e) -> tile, 2: e -> tile.
@@ -273,11 +283,11 @@ __device__ __forceinline__ void fx_expand(const u8* P, const FxX<KS, RT>& X, flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 e[r] = (acc[ct][pt][r] - c[r].x) * c[r].y;
-                v[r] = OUT == 2 ? e[r] : act_f<(OUT == 2 ? 0 : OUT)>(e[r]);
+                v[r] = (OUT == 2 || (FX_ABL & 16)) ? e[r] : act_f<(OUT == 2 ? 0 : OUT)>(e[r]);
             }
             st4(tile + slot[pt] * 32 + 16 * ct + 4 * q, v);
             // (columns between mc and the chunk's end are the group's padding in the [pixels][M] row: zeros may go there)
-            if (eg && pv[pt]) st4_nt(eg + egoff[pt] + 16 * ct + 4 * q, e);
+            if (!(FX_ABL & 4) && eg && pv[pt]) st4_nt(eg + egoff[pt] + 16 * ct + 4 * q, e);
         }
     }
 }
@@ -311,20 +321,29 @@ __device__ __forceinline__ void fx_stat_emit(const float* stat, float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <int K, int ACT, int KS, int RT>
-__device__ __forceinline__ void fx_fwd_stencil(const float* tile, const float* taps, const TfnasCellDesc& d, int HP, int WP,
-                                               int nimg, int img0, int goff, int c0, int mcp, float* __restrict__ D, float* stat) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = lane & 7, k8 = lane >> 3;
-    const int Ho = d.Ho, Wo = d.Wo, M = d.M;
-    const int SCN = (Wo + 3) >> 2, per_img = SCN * Ho, nstrips = nimg * per_img;
-    const bool chok = c0 + 4 * cq < mcp;
+// Seven WORKER waves (pixel tiles wave + 7 pt; one stencil item each) and one COPIER wave (wave 7).  The workers never wait
+// on vector memory inside the chunk loop: they only issue stores (D, ehat).  On gfx950 loads and stores share one counter, so
+// a wave that prefetches the next chunk's blob AND stores results ends every interval in `s_waitcnt vmcnt(0)`, i.e. waiting for
+// its store acknowledgements (ablation, tools/r5_fxabl.sh: the kernel without taps and without MFMAs still took 60 % of its
+// time).  The copier moves the blobs (global -> registers -> LDS, all pieces in flight at once) and writes the statistics rows.
+constexpr int FX_WORKERS = 7;
+
+struct FxFItem {
+    int toff;        // float offset of the window's top-left pixel in the padded image tile (+ 4 cq)
+    unsigned doff;   // element offset of the strip's first output pixel in D, relative to the image group's first pixel row
+    int npx;         // valid pixels of the strip; 0: no item
+};
+
+template <int K>
+__device__ __forceinline__ void fx_fwd_stencil(const float* tile, const float* taps, const FxFItem it, int WP, int M, bool chok,
+                                               float* __restrict__ Dc, float* stat) {
+    const int cq = threadIdx.x & 7;
     f32x4 ssum = zero4(), ssq = zero4();
-    for (int j = wave * 8 + k8; j < nstrips; j += 64) {
-        const int img = j / per_img, r = j - img * per_img, sc = r / Ho, oh = r - sc * Ho, ow0 = 4 * sc;
-        const float* base = tile + ((img * HP + oh) * WP + ow0) * 32 + 4 * cq;
+    if (it.npx > 0) {
+        const float* base = tile + it.toff;
         f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
+        for (int ky = 0; ky < ((FX_ABL & 1) ? 0 : K); ++ky) {
             const float* rowp = base + ky * WP * 32;
             const float* wp = taps + ky * K * 32 + 4 * cq;
             f32x4 win[K + 3];
@@ -338,12 +357,11 @@ __device__ __forceinline__ void fx_fwd_stencil(const float* tile, const float* t
             }
         }
         if (chok) {
-            const int npx = Wo - ow0 < 4 ? Wo - ow0 : 4;
-            float* __restrict__ o = D + ((size_t)((img0 + img) * Ho + oh) * Wo + ow0) * M + goff + c0 + 4 * cq;
+            float* __restrict__ o = Dc + it.doff;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                if (jj < npx) {
-                    st4_nt(o + (size_t)jj * M, acc[jj]);
+                if (jj < it.npx) {
+                    if (!(FX_ABL & 4)) st4_nt(o + (size_t)jj * M, acc[jj]);
                     ssum += acc[jj];
                     ssq += acc[jj] * acc[jj];
                 }
@@ -353,44 +371,242 @@ __device__ __forceinline__ void fx_fwd_stencil(const float* tile, const float* t
     fx_stat_park(ssum, ssq, stat);
 }
 
+// One interval of a worker wave as ONE instruction stream: the MFMAs of chunk i + 1 (k-step by k-step) with the tap rows of chunk i's
+// stencil item between them.  A wave is in-order: run one after the other, its interval is t(MFMA) + t(stencil) however busy the
+// partner wave keeps the other pipe (measured: the two added up exactly, tools/r5_fxabl.sh); in one basic block the scheduler
+// fills the 16-cycle shadow of every v_mfma_f32_16x16x32_bf16 with the stencil's LDS reads and v_pk_fma_f32.
+template <int K, int ACT, int KS, int RT>
+__device__ __forceinline__ void fx_fwd_interval(const u8* P, const FxX<KS, RT>& X, float* tnext, const int (&slot)[RT],
+                                                const bool (&pv)[RT], float* __restrict__ eg, const size_t* egoff, bool do_expand,
+                                                const float* tile, const float* taps, const FxFItem it, int WP, int M, bool chok,
+                                                float* __restrict__ Dc, float* stat) {
+    constexpr int RS = 64 * KS + 32;
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, cq = lane & 7;
+    f32x4 acc[2][RT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < RT; ++pt) acc[ct][pt] = zero4();
+    f32x4 sacc[4] = {zero4(), zero4(), zero4(), zero4()};
+    const float* base = tile + it.toff;
+    auto tap_row = [&](int ky) __attribute__((always_inline)) {
+        const float* rowp = base + ky * WP * 32;
+        const float* wp = taps + ky * K * 32 + 4 * cq;
+        f32x4 win[K + 3];
+#pragma unroll
+        for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const f32x4 wv = ld4(wp + kx * 32);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sacc[jj] += win[jj + kx] * wv;
+        }
+    };
+    // 6 KS groups of 2 RT MFMAs (one split product on every accumulator); tap row ky follows group ((ky + 1) * 6 KS) / K - 1, and a
+    // scheduling barrier closes every group: the scheduler may mix a group's MFMAs with ONE tap row's LDS reads and FMAs, not more
+    // (left alone it hoists every window load to the top: 100-170 spilled registers)
+    constexpr int NG = 6 * KS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const u8* ap = P + (16 * ct + n) * RS + 64 * ks + 16 * q;
+            ah[ct] = *reinterpret_cast<const bf16x8*>(ap);
+            am[ct] = *reinterpret_cast<const bf16x8*>(ap + 32 * RS);
+            al[ct] = *reinterpret_cast<const bf16x8*>(ap + 64 * RS);
+        }
+#define FX_GROUP(T_, A_, B_)                                                                   \
+    {                                                                                          \
+        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) _Pragma("unroll") for (int pt = 0; pt < RT; ++pt)                 \
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[ct], X.B_[pt][ks_c], acc[ct][pt], 0, 0, 0);           \
+        constexpr int G = 6 * ks_c + T_;                                                       \
+        if constexpr (((G + 1) * K) / NG > (G * K) / NG) {                                     \
+            tap_row((G * K) / NG);                                                             \
+            /* pin the row's FMAs here: pure arithmetic floats freely past a scheduling barrier, an asm with side effects not */ \
+            asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(sacc[2]), "+v"(sacc[3]));     \
+        }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+        // (ks is a compile-time constant after unrolling, but not a constant expression: dispatch on it)
+        auto groups = [&](auto ksc) __attribute__((always_inline)) {
+            constexpr int ks_c = decltype(ksc)::value;
+            FX_GROUP(0, al, h) FX_GROUP(1, am, m) FX_GROUP(2, ah, l) FX_GROUP(3, am, h) FX_GROUP(4, ah, m) FX_GROUP(5, ah, h)
+        };
+        if (ks == 0) groups(std::integral_constant<int, 0>{});
+        else if (ks == 1) groups(std::integral_constant<int, 1>{});
+        else if (ks == 2) groups(std::integral_constant<int, 2>{});
+        else if (ks == 3) groups(std::integral_constant<int, 3>{});
+        else if (ks == 4) groups(std::integral_constant<int, 4>{});
+        else groups(std::integral_constant<int, 5>{});
+#undef FX_GROUP
+    }
+    // ---- stencil epilogue: D, BN2 partial sums
+    // (the sums take every strip pixel through a select, not a branch: results that are only used under a condition get SUNK into
+    //  the conditional block by the compiler -- all 200 FMAs of the stencil ended up behind the MFMAs again)
+    f32x4 ssum = zero4(), ssq = zero4();
+    float* __restrict__ o = Dc + it.doff;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const bool ok = chok && jj < it.npx;
+        const f32x4 m = ok ? sacc[jj] : zero4();
+        ssum += m;
+        ssq += m * m;
+        if (ok) st4_nt(o + (size_t)jj * M, sacc[jj]);
+    }
+    fx_stat_park(ssum, ssq, stat);
+    // ---- expand epilogue: BN1 + activation -> next image tile (+ ehat -> E)
+    if (do_expand) {
+        const float2* cst = reinterpret_cast<const float2*>(P + 96 * RS);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float2 c[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = cst[16 * ct + 4 * q + r];
+#pragma unroll
+            for (int pt = 0; pt < RT; ++pt) {
+                f32x4 e, v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (acc[ct][pt][r] - c[r].x) * c[r].y;
+                    v[r] = act_f<ACT>(e[r]);
+                }
+                st4(tnext + slot[pt] * 32 + 16 * ct + 4 * q, v);
+                if (eg && pv[pt]) st4_nt(eg + egoff[pt] + 16 * ct + 4 * q, e);
+            }
+        }
+    }
+}
+
 template <int K, int ACT, int KS, int RT>
 __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan& pl, const float* __restrict__ x,
                                             const u8* __restrict__ blob, float* __restrict__ D, float* __restrict__ part,
                                             u8* lds, int ig, const FxSlice sl, float* __restrict__ Eg) {
     constexpr int PAD = K / 2, RS = 64 * KS + 32, PB = 96 * RS + 256, WBK = K * K * 128;
-    constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16), NVW = 1;
-    static_assert(WBK <= FX_THREADS * 16, "tap blob copy");
+    constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
+    constexpr int NCP = (PB + 1023) / 1024, NCW = (WBK + 1023) / 1024;      // copier: 1 KiB per wave instruction
+    constexpr int NCP1 = NCP < 28 ? NCP : 28;                               // pieces held in registers across the barrier
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M;
+    const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M, Ho = d.Ho, Wo = d.Wo;
     const int HP = H + 2 * PAD, WP = (W + 2 * PAD) | 1;
-    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW, ntiles = (NPX + 15) >> 4;
+    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW;
     const int g = sl.g, mcp = d.g[g].mcp, goff = d.g[g].off, nch = sl.nch;
     // LDS carve-up (sized on the host for the cell's largest kernel size)
     const int PADM = pl.KMAX / 2;
     const size_t tile_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
-    float* T[2] = {reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds + tile_b)};
-    u8* Pb[2] = {lds + 2 * tile_b, lds + 2 * tile_b + pl.PB};
-    u8* Wb[2] = {lds + 2 * tile_b + 2 * pl.PB, lds + 2 * tile_b + 2 * pl.PB + pl.WB};
-    float* St[2] = {reinterpret_cast<float*>(lds + 2 * tile_b + 2 * pl.PB + 2 * pl.WB),
-                    reinterpret_cast<float*>(lds + 2 * tile_b + 2 * pl.PB + 2 * pl.WB + 2048)};
+    // (buffers are picked by OFFSET arithmetic on the one LDS base: a pointer taken from an array of pointers is a generic pointer
+    //  to the compiler, every access through it becomes a FLAT instruction -- slower than ds_read / ds_write and counted in vmcnt,
+    //  i.e. each LDS read then also waits for the global stores in flight: the first version ran 4x slower than its instruction mix)
+    const unsigned tile_u = (unsigned)tile_b, pb_u = (unsigned)pl.PB, wb_u = (unsigned)pl.WB;
+    auto T = [&](int k) { return reinterpret_cast<float*>(lds + (k & 1) * tile_u); };
+    auto Pb = [&](int k) { return lds + 2 * tile_u + (k & 1) * pb_u; };
+    auto Wb = [&](int k) { return lds + 2 * tile_u + 2 * pb_u + (k & 1) * wb_u; };
+    auto St = [&](int k) { return reinterpret_cast<float*>(lds + 2 * tile_u + 2 * pb_u + 2 * wb_u + (k & 1) * 2048u); };
 
+    // zero both image tiles (the halo stays zero; interiors are rewritten per chunk); first blobs
+    for (size_t i = (size_t)tid * 16; i < 2 * tile_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < 2 * 512; i += FX_THREADS) St(0)[i] = 0.f;           // (the copier wave parks nothing: its rows stay zero)
+    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    {
+        FxCopy<NVP> cp;
+        FxCopy<1> cw;
+        cp.load(bl0, PB);
+        cw.load(bl0 + pl.PB, WBK);
+        cp.store(Pb(0), PB);
+        cw.store(Wb(0), WBK);
+        if (nch > 1) {
+            cp.load(bl0 + pl.BLOB, PB);
+            cp.store(Pb(1), PB);
+        }
+    }
+    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+
+    if (wave == FX_WORKERS) {
+        // ------------------------------------------------------------------------------------------------ copier wave
+        __syncthreads();
+        for (int i = 0; i < nch; ++i) {
+            const bool p2 = i + 2 < nch, w1 = i + 1 < nch;
+            u32x4 vp[NCP1], vw[NCW];
+            const u8* sp = bl0 + (size_t)(p2 ? i + 2 : i) * pl.BLOB;
+            const u8* sw = bl0 + (size_t)(w1 ? i + 1 : i) * pl.BLOB + pl.PB;
+#pragma unroll
+            for (int u = 0; u < NCP1; ++u) {
+                const int o = (lane + 64 * u) * 16;
+                vp[u] = *reinterpret_cast<const u32x4*>(sp + (o < PB ? o : PB - 16));
+            }
+#pragma unroll
+            for (int u = 0; u < NCW; ++u) {
+                const int o = (lane + 64 * u) * 16;
+                vw[u] = *reinterpret_cast<const u32x4*>(sw + (o < WBK ? o : WBK - 16));
+            }
+            __syncthreads();
+            if (i > 0 && lane < 64) {                                      // statistics of chunk i - 1 -> this group's partial row
+                const int ch = lane & 31, which = lane >> 5, c0p = sl.c0 + 32 * (i - 1);
+                const float* st = St((i - 1) & 1);
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < FX_WORKERS; ++w) t += st[w * 64 + which * 32 + ch];
+                if (c0p + ch < mcp) prow[2 * (size_t)(c0p + ch) + which] = t;
+            }
+            if (p2 && !(FX_ABL & 8)) {
+                u8* dp = Pb(i & 1);
+#pragma unroll
+                for (int u = 0; u < NCP1; ++u) {
+                    const int o = (lane + 64 * u) * 16;
+                    if (o < PB) *reinterpret_cast<u32x4*>(dp + o) = vp[u];
+                }
+                if (NCP > NCP1) {                      // (wide blobs: the tail in a second batch -- this wave has nothing else to do)
+                    u32x4 vq[NCP > NCP1 ? NCP - NCP1 : 1];
+#pragma unroll
+                    for (int u = NCP1; u < NCP; ++u) {
+                        const int o = (lane + 64 * u) * 16;
+                        vq[u - NCP1] = *reinterpret_cast<const u32x4*>(sp + (o < PB ? o : PB - 16));
+                    }
+#pragma unroll
+                    for (int u = NCP1; u < NCP; ++u) {
+                        const int o = (lane + 64 * u) * 16;
+                        if (o < PB) *reinterpret_cast<u32x4*>(dp + o) = vq[u - NCP1];
+                    }
+                }
+            }
+            if (w1 && !(FX_ABL & 8)) {
+                u8* dw = Wb((i + 1) & 1);
+#pragma unroll
+                for (int u = 0; u < NCW; ++u) {
+                    const int o = (lane + 64 * u) * 16;
+                    if (o < WBK) *reinterpret_cast<u32x4*>(dw + o) = vw[u];
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int ch = lane & 31, which = lane >> 5, c0p = sl.c0 + 32 * (nch - 1);
+            const float* st = St((nch - 1) & 1);
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < FX_WORKERS; ++w) t += st[w * 64 + which * 32 + ch];
+            if (c0p + ch < mcp) prow[2 * (size_t)(c0p + ch) + which] = t;
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- worker waves
     // pixels of the wave's tiles: LDS slot (padded image coordinates) and validity
     int slot[RT];
     bool pv[RT];
     size_t egoff[RT];                                  // stored-ehat mode: the pixel's row in the [pixels][M] tensor
 #pragma unroll
     for (int pt = 0; pt < RT; ++pt) {
-        const int p = 16 * (wave + 8 * pt) + n;
+        const int p = 16 * (wave + FX_WORKERS * pt) + n;
         pv[pt] = p < NPX;
         const int img = p / HW, r = p - img * HW, h = r / W, w = r - h * W;
-        slot[pt] = pv[pt] ? (img * HP + h + PAD) * WP + w + PAD : pl.NI * (H + 2 * (pl.KMAX / 2)) * ((W + 2 * (pl.KMAX / 2)) | 1) + 4;
+        slot[pt] = pv[pt] ? (img * HP + h + PAD) * WP + w + PAD : pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 4;
         egoff[pt] = ((size_t)img0 * HW + p) * M + goff;
     }
     // x rows -> split planes (registers, once)
     FxX<KS, RT> X;
 #pragma unroll
     for (int pt = 0; pt < RT; ++pt) {
-        const int p = 16 * (wave + 8 * pt) + n;
+        const int p = 16 * (wave + FX_WORKERS * pt) + n;
         const float* __restrict__ xp = x + ((size_t)img0 * HW + p) * ic + 8 * q;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -399,48 +615,31 @@ __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan
             fx_split8(a, b, X.h[pt][ks], X.m[pt][ks], X.l[pt][ks]);
         }
     }
-    // zero both image tiles (the halo stays zero; interiors are rewritten per chunk)
-    for (size_t i = (size_t)tid * 16; i < 2 * tile_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0, 0, 0, 0};
-    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    // the wave's stencil items: strip (wave * 8 + lane / 8), channel quad lane % 8 -- the same in every chunk
+    FxFItem it;
     {
-        FxCopy<NVP> cp;
-        FxCopy<NVW> cw;
-        cp.load(bl0, PB);
-        cw.load(bl0 + pl.PB, WBK);
-        cp.store(Pb[0], PB);
-        cw.store(Wb[0], WBK);
-        if (nch > 1) {
-            cp.load(bl0 + pl.BLOB, PB);
-            cp.store(Pb[1], PB);
-        }
+        const int j = wave * 8 + (lane >> 3), cq = lane & 7;
+        const int SCN = (Wo + 3) >> 2, per_img = SCN * Ho;
+        const int img = j / per_img, r = j - img * per_img, sc = r / Ho, oh = r - sc * Ho, ow0 = 4 * sc;
+        it.npx = j < nimg * per_img ? (Wo - ow0 < 4 ? Wo - ow0 : 4) : 0;
+        it.toff = ((img * HP + oh) * WP + ow0) * 32 + 4 * cq;
+        it.doff = (unsigned)(((img * Ho + oh) * Wo + ow0) * M + 4 * cq);
     }
+    float* __restrict__ Dg = D + (size_t)img0 * Ho * Wo * M + goff;
+    const int cq = lane & 7;
     __syncthreads();
-    fx_expand<KS, RT, ACT>(Pb[0], X, T[0], slot, pv, ntiles, Eg ? Eg + sl.c0 : nullptr, egoff, mcp - sl.c0);
-    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+    fx_expand<KS, RT, ACT>(Pb(0), X, T(0), slot, pv, 0, Eg ? Eg + sl.c0 : nullptr, egoff, 0);
     for (int i = 0; i < nch; ++i) {
-        // interval i: stencil of chunk i  ||  MFMAs of chunk i + 1;  planes of chunk i + 2 and taps of chunk i + 1 on their way
-        FxCopy<NVP> cp;
-        FxCopy<NVW> cw;
-        const bool p2 = i + 2 < nch, w1 = i + 1 < nch;
-        cp.load(bl0 + (size_t)(p2 ? i + 2 : i) * pl.BLOB, PB);              // (always issued: see FxCopy)
-        cw.load(bl0 + (size_t)(w1 ? i + 1 : i) * pl.BLOB + pl.PB, WBK);
+        // interval i: stencil of chunk i  ||  MFMAs of chunk i + 1  (the copier brings planes of chunk i + 2, taps of chunk i + 1)
+        const bool w1 = i + 1 < nch;
         __syncthreads();
-        if (i > 0) fx_stat_emit(St[(i - 1) & 1], prow, sl.c0 + 32 * (i - 1), mcp);
         const int c0 = sl.c0 + 32 * i;
-        if (wave < 4) {
-            fx_fwd_stencil<K, ACT, KS, RT>(T[i & 1], reinterpret_cast<const float*>(Wb[i & 1]), d, HP, WP, nimg, img0, goff, c0,
-                                           mcp, D, St[i & 1]);
-            if (w1) fx_expand<KS, RT, ACT>(Pb[(i + 1) & 1], X, T[(i + 1) & 1], slot, pv, ntiles, Eg ? Eg + c0 + 32 : nullptr, egoff, mcp - c0 - 32);
-        } else {
-            if (w1) fx_expand<KS, RT, ACT>(Pb[(i + 1) & 1], X, T[(i + 1) & 1], slot, pv, ntiles, Eg ? Eg + c0 + 32 : nullptr, egoff, mcp - c0 - 32);
-            fx_fwd_stencil<K, ACT, KS, RT>(T[i & 1], reinterpret_cast<const float*>(Wb[i & 1]), d, HP, WP, nimg, img0, goff, c0,
-                                           mcp, D, St[i & 1]);
-        }
-        if (p2) cp.store(Pb[i & 1], PB);
-        if (w1) cw.store(Wb[(i + 1) & 1], WBK);
+        const bool chok = c0 + 4 * cq < mcp;
+        // (the last interval runs the MFMAs on the stale planes of the buffer and drops the result: no branch in the stream)
+        fx_fwd_interval<K, ACT, KS, RT>(Pb((i + 1) & 1), X, T((i + 1) & 1), slot, pv, Eg ? Eg + c0 + 32 : nullptr, egoff, w1,
+                                        T(i & 1), reinterpret_cast<const float*>(Wb(i & 1)), it, WP, M, chok, Dg + c0, St(i & 1));
     }
     __syncthreads();
-    fx_stat_emit(St[(nch - 1) & 1], prow, sl.c0 + 32 * (nch - 1), mcp);
 }
 
 template <int ACT, int KS, int RT>
@@ -546,12 +745,14 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
     const int nt16a = ((pl.NI * HW + 15) / 16) * 16;
     const size_t eh_b = (size_t)(nt16a + 16) * 128;
     const size_t dd_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
-    float* EH[2] = {reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds + eh_b)};
+    const unsigned eh_u = (unsigned)eh_b;
+    auto EH = [&](int k) { return reinterpret_cast<float*>(lds + (k & 1) * eh_u); };       // (offset arithmetic: see fx_fwd_body)
     float* DD = reinterpret_cast<float*>(lds + 2 * eh_b);
     u8* Pb = lds + 2 * eh_b + dd_b;
     u8* Wr = Pb + pl.PB;
     f32x4* C2 = reinterpret_cast<f32x4*>(Wr + WRB);
-    u8* Wb[2] = {Wr + WRB + 512, Wr + WRB + 512 + pl.WB};
+    const unsigned wb_u = (unsigned)pl.WB;
+    auto Wb = [&](int k) { return Wr + WRB + 512 + (k & 1) * wb_u; };
     float* St = reinterpret_cast<float*>(Wr + WRB + 512 + 2 * pl.WB);
 
     int slot[RT], prw[RT];                           // (compact tile: the pixel's own index; tiles past the end: the spare tile)
@@ -604,7 +805,7 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
         cw.load(bl0 + pl.PB, WBK);
         cc.load(bl0 + pl.PB + pl.WB, 512);
         cp.store(Pb, PB);
-        cw.store(Wb[0], WBK);
+        cw.store(Wb(0), WBK);
         cc.store(reinterpret_cast<u8*>(C2), 512);
     }
     f32x4 dx[CT][RT];
@@ -632,7 +833,7 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
         }
         if (i > 0) {
             fx_stat_emit(St, prow, c0 - 32, mcp);
-            const float* eh = EH[(i - 1) & 1];
+            const float* eh = EH((i - 1) & 1);
             bf16x8 bh[RT], bm[RT], bl[RT];
 #pragma unroll
             for (int pt = 0; pt < RT; ++pt) {
@@ -653,7 +854,7 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
             }
         }
         if (i == nch) break;
-        fx_expand<KS, RT, 2>(Pb, X, EH[i & 1], slot, pv, ntiles);
+        fx_expand<KS, RT, 2>(Pb, X, EH(i & 1), slot, pv, ntiles);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (lslot[r] >= 0) {
@@ -683,11 +884,11 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
             cw.load(bi + pl.BLOB + pl.PB, WBK);
             cc.load(bi + pl.BLOB + pl.PB + pl.WB, 512);
         }
-        fx_bwd_stencil<K, ACT>(DD, reinterpret_cast<const float*>(Wb[i & 1]), EH[i & 1], it, WP, St);
+        fx_bwd_stencil<K, ACT>(DD, reinterpret_cast<const float*>(Wb(i & 1)), EH(i & 1), it, WP, St);
         cr.store(Wr, WRB);
         if (nx) {
             cp.store(Pb, PB);
-            cw.store(Wb[(i + 1) & 1], WBK);
+            cw.store(Wb((i + 1) & 1), WBK);
             cc.store(reinterpret_cast<u8*>(C2), 512);
         }
         __syncthreads();
@@ -739,7 +940,8 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
     float* DD = reinterpret_cast<float*>(lds + de_b);
     u8* Wr = lds + de_b + dd_b;
     f32x4* C2 = reinterpret_cast<f32x4*>(Wr + WRB);
-    u8* Wb[2] = {Wr + WRB + 512, Wr + WRB + 512 + pl.WB};
+    const unsigned wb_u = (unsigned)pl.WB;
+    auto Wb = [&](int k) { return Wr + WRB + 512 + (k & 1) * wb_u; };
     float* St = reinterpret_cast<float*>(Wr + WRB + 512 + 2 * pl.WB);
 
     int prow_[RT];
@@ -779,7 +981,7 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         FxCopy<1> cw, cc;
         cw.load(bl0 + pl.PB, WBK);
         cc.load(bl0 + pl.PB + pl.WB, 512);
-        cw.store(Wb[0], WBK);
+        cw.store(Wb(0), WBK);
         cc.store(reinterpret_cast<u8*>(C2), 512);
     }
     f32x4 dx[CT][RT];
@@ -861,7 +1063,7 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         cw.load(bn + pl.PB, WBK);
         cc.load(bn + pl.PB + pl.WB, 512);
         {
-            const float* taps = reinterpret_cast<const float*>(Wb[i & 1]);
+            const float* taps = reinterpret_cast<const float*>(Wb(i & 1));
             f32x4 t1 = zero4(), t2 = zero4();
             if (it.npx > 0) {
                 const float* base = DD + it.toff;
@@ -900,7 +1102,7 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         }
         cr.store(Wr, WRB);
         if (nx) {
-            cw.store(Wb[(i + 1) & 1], WBK);
+            cw.store(Wb((i + 1) & 1), WBK);
             cc.store(reinterpret_cast<u8*>(C2), 512);
         }
         __syncthreads();
@@ -949,88 +1151,135 @@ __global__ __launch_bounds__(FX_THREADS) void k_fx_bwd(TfnasCellDesc d, FxPlan p
 template <int CT>
 __global__ __launch_bounds__(256) void k_fx_gram(const float* __restrict__ x, int P, int ic, int rps,
                                                  const double* __restrict__ xsum, float* __restrict__ part) {
-    constexpr int JT = (CT + 3) / 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    // grid = (row blocks, 4): workgroup y owns the column tiles j = y, y + 4, ..; its wave w the row tiles i = w, w + 4, ..
+    constexpr int NT = (CT + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, jy = blockIdx.y;
     const int r0 = blockIdx.x * rps, r1 = min(P, r0 + rps);
-    float mu[CT];
+    float mui[NT], muj[NT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) mu[t] = (float)(xsum[16 * t + n] / (double)P);
-    f32x4 acc[CT][JT];
+    for (int t = 0; t < NT; ++t) {
+        const int it = wave + 4 * t, jt = jy + 4 * t;
+        mui[t] = it < CT ? (float)(xsum[16 * it + n] / (double)P) : 0.f;
+        muj[t] = jt < CT ? (float)(xsum[16 * jt + n] / (double)P) : 0.f;
+    }
+    f32x4 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < CT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < JT; ++j) acc[i][j] = zero4();
-    for (int p = r0; p < r1; p += 4) {
-        const int row = p + q;
-        float a[CT];
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+    // 16 rows per iteration: all their loads are issued before the first MFMA (one dependent L2 round trip per iteration, not four)
+    for (int p = r0; p < r1; p += 16) {
+        float a[4][NT], b[4][NT];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) a[t] = row < r1 ? x[(size_t)row * ic + 16 * t + n] - mu[t] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int row = p + 4 * u + q;
+            const float* __restrict__ xr = x + (size_t)(row < r1 ? row : r1 - 1) * ic + n;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            const int jt = wave + 4 * j;
-            if (jt < CT) {
-                // (a[jt] with a run-time index would go through scratch: select it)
-                float bj = 0.f;
-#pragma unroll
-                for (int t = 0; t < CT; ++t) bj = t == jt ? a[t] : bj;
-#pragma unroll
-                for (int i = 0; i < CT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bj, acc[i][j], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                const int it = wave + 4 * t, jt = jy + 4 * t;
+                const float va = xr[16 * (it < CT ? it : 0)], vb = xr[16 * (jt < CT ? jt : 0)];
+                a[u][t] = (row < r1 && it < CT) ? va - mui[t] : 0.f;
+                b[u][t] = (row < r1 && jt < CT) ? vb - muj[t] : 0.f;
             }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
     }
-    // acc[i][j][r] of lane (n, q) = C[16 i + 4 q + r][16 (wave + 4 j) + n]
+    // acc[i][j][r] of lane (n, q) = C[16 (wave + 4 i) + 4 q + r][16 (jy + 4 j) + n]
     float* __restrict__ out = part + (size_t)blockIdx.x * ic * ic;
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const int jt = wave + 4 * j;
-        if (jt < CT) {
+    for (int i = 0; i < NT; ++i) {
+        const int it = wave + 4 * i;
 #pragma unroll
-            for (int i = 0; i < CT; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const int jt = jy + 4 * j;
+            if (it < CT && jt < CT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[(size_t)(16 * i + 4 * q + r) * ic + 16 * jt + n] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) out[(size_t)(16 * it + 4 * q + r) * ic + 16 * jt + n] = acc[i][j][r];
+            }
         }
     }
 }
 
-// stats1[2 col] = sum_p E, [2 col + 1] = sum_p E^2 for 32 channels per workgroup: thread = (channel, eighth of the rows of C)
-__global__ __launch_bounds__(256) void k_fx_stats1(TfnasCellDesc d, const double* __restrict__ xsum, const double* __restrict__ C,
-                                                   double* __restrict__ stats1) {
-    __shared__ double red[2][8][32];
-    const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5, ic = d.ic;
-    const int col = blockIdx.x * 32 + cl;
+// stats1[2 col] = sum_p E, [2 col + 1] = sum_p E^2 = w_m^T C w_m + (sum)^2 / P.  T = W C on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64; gfx950 runs VECTOR fp64 FMAs at a small fraction of that rate: four vector-FMA forms of this kernel
+// took 50-290 us): one wave per 16 channels, CT = ic / 16 column tiles of T in registers, A = the 16 weight rows (fp32 -> fp64
+// on load), B = rows of C (every wave streams the same C: L2); then q_m = <T_m, w_m> lane-wise + a 16-lane reduction.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ const float* fx_wrow(const TfnasCellDesc& d, int col) {
+    if (col >= d.M) return nullptr;
     int g = 0;
     for (; g < d.G - 1; ++g)
         if (col < d.g[g + 1].off) break;
     const int m = col - d.g[g].off;
-    const bool ok = col < d.M && m >= 0 && m < d.g[g].mc;
-    double s = 0.0, qf = 0.0;
-    if (ok) {
-        const float* __restrict__ w = d.g[g].w_expand + (size_t)m * ic;
-        const int per = (ic + 7) / 8, ca = part * per, cb = min(ic, ca + per);
-        for (int c = ca; c < cb; ++c) {
-            const double* __restrict__ row = C + (size_t)c * ic;
-            double t0 = 0.0, t1 = 0.0;
-            for (int c2 = 0; c2 < ic; c2 += 2) {
-                t0 += row[c2] * (double)w[c2];
-                t1 += row[c2 + 1] * (double)w[c2 + 1];
-            }
-            qf += (double)w[c] * (t0 + t1);
-            s += (double)w[c] * xsum[c];
+    return (m >= 0 && m < d.g[g].mc) ? d.g[g].w_expand + (size_t)m * d.ic : nullptr;
+}
+template <int CT>
+__global__ __launch_bounds__(64) void k_fx_stats1(TfnasCellDesc d, const double* __restrict__ xsum, const double* __restrict__ C,
+                                                  double* __restrict__ stats1) {
+    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4, ic = d.ic, col0 = blockIdx.x * 16;
+    const float* __restrict__ wa = fx_wrow(d, col0 + n);                 // A operand: row n, k = q
+    f64x4 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const float* __restrict__ wac = wa ? wa : d.g[0].w_expand;           // (always a valid address: the load is unconditional)
+    // operands of three k-steps in flight (the loop is a chain of L2 round trips otherwise: 48 steps x ~1.2 us at ic = 192)
+    constexpr int PD = 3;
+    float an[PD];
+    double bn[PD][CT];
+    const int nks = ic >> 2;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        const int k = 4 * (u < nks ? u : nks - 1) + q;
+        an[u] = wac[k];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) bn[u][t] = C[(size_t)k * ic + n + 16 * t];
+    }
+    for (int ks = 0; ks < nks; ks += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const bool live = ks + u < nks;                                 // (wave-uniform; a dead step multiplies by a = 0)
+            const double a = (wa && live) ? (double)an[u] : 0.0;
+            double b[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) b[t] = bn[u][t];
+            const int kn = ks + u + PD;
+            const int k = 4 * (kn < nks ? kn : nks - 1) + q;
+            an[u] = wac[k];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) bn[u][t] = C[(size_t)k * ic + n + 16 * t];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
         }
     }
-    red[0][part][cl] = s;
-    red[1][part][cl] = qf;
-    __syncthreads();
-    if (tid < 32 && col < d.M) {
-        double ss = 0.0, qq = 0.0;
-        for (int p = 0; p < 8; ++p) {
-            ss += red[0][p][cl];
-            qq += red[1][p][cl];
+    // acc[t][i] = T[row q + 4 i][column 16 t + n]
+    const double P = (double)d.N * d.H * d.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = col0 + q + 4 * i;
+        const float* __restrict__ wr = fx_wrow(d, col);
+        double qf = 0.0, sm = 0.0;
+        if (wr) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const double wv = (double)wr[16 * t + n];
+                qf += acc[t][i] * wv;
+                sm += wv * xsum[16 * t + n];
+            }
         }
-        const double P = (double)d.N * d.H * d.W;
-        if (ok) qq += ss * ss / P;                                   // sum E^2 = centred sum of squares + P mean^2
-        stats1[2 * (size_t)col + 0] = ok ? ss : 0.0;
-        stats1[2 * (size_t)col + 1] = ok ? qq : 0.0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            qf += __shfl_xor(qf, o, 64);
+            sm += __shfl_xor(sm, o, 64);
+        }
+        if (n == 0 && col < d.M) {
+            stats1[2 * (size_t)col + 0] = sm;
+            stats1[2 * (size_t)col + 1] = qf + sm * sm / P;
+        }
     }
 }
 
@@ -1054,7 +1303,7 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
         ProfScope _prof(TK_EXPAND_FWD, s);
         const int CT = ic / 16;
         switch (CT) {
-#define FX_GRAM(N_) case N_: hipLaunchKernelGGL(k_fx_gram<N_>, dim3(nb), dim3(256), 0, s, x, P, ic, rps, xsum, part); break;
+#define FX_GRAM(N_) case N_: hipLaunchKernelGGL(k_fx_gram<N_>, dim3(nb, 4), dim3(256), 0, s, x, P, ic, rps, xsum, part); break;
             FX_GRAM(4) FX_GRAM(5) FX_GRAM(6) FX_GRAM(7) FX_GRAM(8) FX_GRAM(9) FX_GRAM(10) FX_GRAM(11) FX_GRAM(12)
 #undef FX_GRAM
             default: return TFNAS_EINVAL;
@@ -1063,7 +1312,12 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
     rc = launch_reduce_rows(part, nb, ne, (size_t)ne, Cm, nullptr, s);
     if (rc) return rc;
     ProfScope _prof(TK_SMALL, s);
-    hipLaunchKernelGGL(k_fx_stats1, dim3(cdiv(d.M, 32)), dim3(256), 0, s, d, xsum, Cm, stats1);
+    switch (ic / 16) {
+#define FX_ST1(N_) case N_: hipLaunchKernelGGL(k_fx_stats1<N_>, dim3(cdiv(d.M, 16)), dim3(64), 0, s, d, xsum, Cm, stats1); break;
+        FX_ST1(4) FX_ST1(5) FX_ST1(6) FX_ST1(7) FX_ST1(8) FX_ST1(9) FX_ST1(10) FX_ST1(11) FX_ST1(12)
+#undef FX_ST1
+        default: return TFNAS_EINVAL;
+    }
     return (int)hipGetLastError();
 }
 
@@ -1080,7 +1334,7 @@ int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, 
     u8* blob = reinterpret_cast<u8*>(part + rows);
     {
         ProfScope _prof(TK_SMALL, s);
-        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks), dim3(256), 0, s, d, pl, stats1, (const double*)nullptr,
+        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks, 4), dim3(256), 0, s, d, pl, stats1, (const double*)nullptr,
                            (const double*)nullptr, blob);
     }
     const size_t shm = fx_fwd_lds(d, pl);
@@ -1097,7 +1351,7 @@ int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, 
     {                                                                            \
         if (d.act == TFNAS_ACT_RELU) FX_FWD(0, KS_, RT_) else FX_FWD(1, KS_, RT_) \
     }
-        const int key = pl.KS * 10 + pl.RT;
+        const int key = pl.KS * 10 + pl.RTF;
         switch (key) {
             case 21: FX_FWD_A(2, 1) break;
             case 22: FX_FWD_A(2, 2) break;
@@ -1173,7 +1427,7 @@ int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const
     u8* blob = reinterpret_cast<u8*>(bo_s != ~(size_t)0 ? scratch + bo_s : part + bo_p);
     {
         ProfScope _prof(TK_SMALL, s);
-        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks), dim3(256), 0, s, d, pl, stats1, stats2, red2, blob);
+        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks, 4), dim3(256), 0, s, d, pl, stats1, stats2, red2, blob);
     }
     const size_t shm = Eh ? fx_bwde_lds(d, pl) : fx_bwd_lds(d, pl);
     const dim3 grid(pl.nig * pl.nslices);
