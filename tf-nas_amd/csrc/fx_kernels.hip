@@ -993,21 +993,27 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
 
     const size_t pixbase = (size_t)img0 * HW;
     float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+    // (all global loads are issued one phase before their use: dZ / D of chunk i + 1 at the top of phase B(i), ehat of chunk i at
+    //  the top of phase A(i) -- with loads issued and consumed inside one phase the kernel without ANY arithmetic still took 70 % of
+    //  its time, tools/r5_fxabl.sh)
+    f32x4 dz[NR], dv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t a = (pixbase + lpix[r]) * M + goff + sl.c0 + 4 * cq;
+        dz[r] = ld4_nt(dZ + a);
+        dv[r] = ld4_nt(Dt + a);
+    }
     for (int i = 0; i <= nch; ++i) {
         const int c0 = sl.c0 + 32 * i;
         const bool chok = c0 + 4 * cq < mcp;
-        // ---- phase A
-        f32x4 dz[NR], dv[NR];
-        if (i < nch) {
+        // ---- phase A: dd(i) -> LDS  ||  dx += dE(i - 1) Wr(i - 1)   (the two halves of the workgroup in opposite order)
+        f32x4 ev[4];
+        {
+            const int ce = i < nch ? c0 : c0 - 32;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const size_t a = (pixbase + lpix[r]) * M + goff + c0 + 4 * cq;       // (in-bounds for every lane: clamped pixel)
-                dz[r] = ld4_nt(dZ + a);
-                dv[r] = ld4_nt(Dt + a);
-            }
+            for (int jj = 0; jj < 4; ++jj) ev[jj] = ld4_nt(Eh + eaddr + ce + (size_t)(jj < it.npx ? jj : 0) * M);
         }
-        if (i > 0) {
-            fx_stat_emit(St, prow, c0 - 32, mcp);
+        auto gstep = [&]() __attribute__((always_inline)) {
             bf16x8 bh[RT], bm[RT], bl[RT];
 #pragma unroll
             for (int pt = 0; pt < RT; ++pt) {
@@ -1027,37 +1033,42 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
                 }
 #define FX_GTERM(A_, B_)                                                                                             \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int pt = 0; pt < RT; ++pt) {                \
-        if (ct0 + u < CT)                                                                                            \
+        if (ct0 + u < CT && !(FX_ABL & 32))                                                                          \
             dx[ct0 + u < CT ? ct0 + u : ct0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
                 A_[u], B_[pt], dx[ct0 + u < CT ? ct0 + u : ct0][pt], 0, 0, 0);                                       \
     }
                 FX_GTERM(al, bh) FX_GTERM(am, bm) FX_GTERM(ah, bl) FX_GTERM(am, bh) FX_GTERM(ah, bm) FX_GTERM(ah, bh)
 #undef FX_GTERM
             }
-        }
-        if (i == nch) break;
+        };
+        auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            if (lslot[r] >= 0) {
-                f32x4 g4 = zero4(), dp4 = zero4();
-                if (has_se) {
-                    const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
-                    g4 = ld4(gate + o);
-                    dp4 = ld4(dpooled + o) * splat4(inv_hw);
+            for (int r = 0; r < NR; ++r) {
+                if (lslot[r] >= 0) {
+                    f32x4 g4 = zero4(), dp4 = zero4();
+                    if (has_se) {
+                        const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
+                        g4 = ld4(gate + o);
+                        dp4 = ld4(dpooled + o) * splat4(inv_hw);
+                    }
+                    f32x4 v = (FX_ABL & 128) ? dz[r] + dv[r] : fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
+                    if (!chok) v = zero4();
+                    st4(DD + lslot[r], v);
                 }
-                f32x4 v = fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
-                if (!chok) v = zero4();
-                st4(DD + lslot[r], v);
             }
-        }
+        };
+        // (loads are consumed in the order they were issued -- the vector-memory counter is in-order, a wait for an older load
+        //  must not find younger ones it would have to wait for as well: dZ / D (i) [end of phase B(i-1)] -> ehat (i) [here] ->
+        //  blob pieces [top of phase B(i)] -> dZ / D (i+1) [end of phase B(i)])
+        if (i > 0) fx_stat_emit(St, prow, c0 - 32, mcp);
+        if (i > 0) gstep();
+        if (i == nch) break;
+        commit();
         __syncthreads();
-        // ---- phase B
-        f32x4 ev[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ev[jj] = ld4_nt(Eh + eaddr + c0 + (size_t)(jj < it.npx ? jj : 0) * M);
+        // ---- phase B: stencil of chunk i; the next blob pieces arrive meanwhile, dZ / D of chunk i + 1 are requested at its end
+        const bool nx = i + 1 < nch;
         FxCopy<NVR> cr;
         FxCopy<1> cw, cc;
-        const bool nx = i + 1 < nch;
         const u8* bi = bl0 + (size_t)i * pl.BLOB, *bn = bl0 + (size_t)(nx ? i + 1 : i) * pl.BLOB;
         cr.load(bi + pl.PB + pl.WB + 512, WRB);
         cw.load(bn + pl.PB, WBK);
@@ -1065,38 +1076,32 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         {
             const float* taps = reinterpret_cast<const float*>(Wb(i & 1));
             f32x4 t1 = zero4(), t2 = zero4();
-            if (it.npx > 0) {
-                const float* base = DD + it.toff;
-                f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+            const float* base = DD + it.toff;
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
 #pragma unroll 1
-                for (int ky = 0; ky < K; ++ky) {
-                    const float* rowp = base + ky * WP * 32;
-                    const float* wp = taps + (K * K - 1 - ky * K) * 32 + 4 * cq;      // flipped taps
-                    f32x4 win[K + 3];
+            for (int ky = 0; ky < ((FX_ABL & 64) ? 0 : K); ++ky) {
+                const float* rowp = base + ky * WP * 32;
+                const float* wp = taps + (K * K - 1 - ky * K) * 32 + 4 * cq;      // flipped taps
+                f32x4 win[K + 3];
 #pragma unroll
-                    for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
+                for (int u = 0; u < K + 3; ++u) win[u] = ld4(rowp + u * 32);
 #pragma unroll
-                    for (int kx = 0; kx < K; ++kx) {
-                        const f32x4 wv = ld4(wp - kx * 32);
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 wv = ld4(wp - kx * 32);
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
-                    }
+                    for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
                 }
+            }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    if (jj < it.npx) {
-                        f32x4 de = zero4();
-                        if (chok) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool ok = chok && jj < it.npx;
+                f32x4 de;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                de[r] = acc[jj][r] * act_d<ACT>(ev[jj][r]);
-                                t1[r] += de[r];
-                                t2[r] += de[r] * ev[jj][r];
-                            }
-                        }
-                        st4(DE + it.eoff + jj * 32, de);
-                    }
-                }
+                for (int r = 0; r < 4; ++r) de[r] = ok ? acc[jj][r] * act_d<ACT>(ev[jj][r]) : 0.f;
+                t1 += de;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t2[r] += ok ? de[r] * ev[jj][r] : 0.f;
+                if (jj < it.npx) st4(DE + it.eoff + jj * 32, de);
             }
             fx_stat_park(t1, t2, St);
         }
@@ -1104,6 +1109,15 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         if (nx) {
             cw.store(Wb((i + 1) & 1), WBK);
             cc.store(reinterpret_cast<u8*>(C2), 512);
+        }
+        {
+            const int cn = nx ? c0 + 32 : c0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const size_t a = (pixbase + lpix[r]) * M + goff + cn + 4 * cq;
+                dz[r] = ld4_nt(dZ + a);
+                dv[r] = ld4_nt(Dt + a);
+            }
         }
         __syncthreads();
     }
@@ -1390,9 +1404,9 @@ static bool fx_bwd_layout(const TfnasCellDesc& d, const FxPlan& pl, size_t scrat
     return true;
 }
 
-// TFNAS_FX = 1 | 0: the fused per-image route for the frozen-weight launches it covers / never
+// TFNAS_FX = 1 (default) | 0: the fused per-image route for the frozen-weight launches it covers / never
 #ifndef TFNAS_FX_DEFAULT
-#define TFNAS_FX_DEFAULT 0
+#define TFNAS_FX_DEFAULT 1
 #endif
 static bool fx_enabled() {
     static const bool on = [] {
