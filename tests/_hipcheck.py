@@ -282,12 +282,13 @@ def fp64_kink_check(o, x, r, e, idxs, res, kink_tau, tol_rel=1e-3):
     return n_dis, n_mask
 
 
-def worst(res, rtol=1e-3, atol=2e-5):
-    """Entries whose abs error exceeds atol + rtol*ref_max."""
+def worst(res, rtol=1e-4, atol=2e-5):
+    """Entries whose abs error exceeds atol + rtol*ref_max.  The north_star's contract is 1e-3 (fp32); the fp32 / split-bf16 paths
+    are gated 10x tighter (observed errors are ~1e-6): a regression shows up an order of magnitude earlier."""
     return {k: v for k, v in res.items() if not k.startswith('_') and not (v[0] <= atol + rtol * v[1])}
 
 
-def check_cell(o, m, x, r, e, idxs, need_wgrad, kink_tau=4e-6, rtol=1e-3, atol=2e-5, max_kink_fraction=None):
+def check_cell(o, m, x, r, e, idxs, need_wgrad, kink_tau=4e-6, rtol=1e-4, atol=2e-5, max_kink_fraction=None):
     """compare_cell + the assertions every cell test makes: nothing beyond tolerance; ReLU launches with a materialised E are
     compared strictly under replayed ReLU decisions; E-free ReLU launches outside the oracle's near-kink elements, with the
     mask validated against an fp64 run of the oracle (and the excluded pixel fraction bounded)."""

@@ -142,6 +142,9 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
         if not p.is_contiguous():
             raise RuntimeError('tfnas_amd: MBConv weights must be contiguous')
     plan.bind(d, params)
+    # the forward must know whether the backward will want weight gradients: the library picks its route per launch (the fused
+    # per-image kernels of the late cells run with frozen weights only and leave ehat, not E, in the E buffer)
+    d.need_wgrad = int(any(ctx.needs_input_grad[3:]))
     dev = xh.device
     _same_device(dev, list(params) + [wmix], 'a MixedOP weight / mix weight')
     # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
@@ -162,6 +165,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     with _on(dev):
         check(_lib.lib().tfnas_mixedop_fwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
                                            ptr(stats), ptr(part), ptr(out), _stream(dev)), 'tfnas_mixedop_fwd')
+    d.need_wgrad = 0
     ctx.plan, ctx.shape, ctx.has_w = plan, (N, H, W), wmix is not None
     if MixedOpFn.fwd_sink is not None:
         MixedOpFn.fwd_sink.append(dict(plan=plan, d=d, ws=ws, E=E, D=D, stats=stats, fsmall=fsmall, shape=(N, d.H, d.W)))

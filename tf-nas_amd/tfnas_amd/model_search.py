@@ -208,7 +208,6 @@ class MixedStage(nn.Module):
 # Network.forward on the path level when it can (GPU model, tfnas_amd.search.USE_PATHS): TFNAS_MODULE_PATHS=0
 # keeps the per-cell route (one autograd node per MixedOP: what the stage-by-stage tests hook into)
 MODULE_PATHS = os.environ.get('TFNAS_MODULE_PATHS', '1') != '0'
-_LAST_PRIVATE = None                    # weakref to the SearchState the drop-in forward built last (Network._path_state)
 SECOND_PATH_ON_SIDE_STREAM = True       # the 'random' forward of a bi-sampling pair on a second HIP stream (tests flip it)
 
 
@@ -393,19 +392,14 @@ class Network(nn.Module):
         """The SearchState (weight arena + path runner, search.py / path.py) the drop-in ``forward`` runs on: the one a caller
         built with ``search.SearchState(model)`` if there is one (it registers itself), else a private one."""
         from . import search
-        global _LAST_PRIVATE
         st = self.__dict__.get('_pstate')
         if st is None or st.runner is None or st.model is not self:
-            # a private state per model: release the previous model's (its weight arena -- 3x the weights --, the path arenas --
-            # GBs at B = 128 -- and the HIP streams / events sit in a model <-> state reference cycle that only Python's cyclic
-            # collector would free, e.g. one model per epoch in a driver loop)
-            prev = _LAST_PRIVATE() if _LAST_PRIVATE is not None else None
-            if prev is not None and prev.model is not self:
-                prev.release()
-            st = search.SearchState(self)
+            # a private state per model, owned by the model: it holds the model weakly, so it is freed (path contexts, arenas,
+            # weight arena -- GBs at B = 128) with the model, by reference counting, and never while another model that is still in
+            # use would need it (a teacher and a student, an EMA copy evaluated between forward and backward, ...)
+            st = search.SearchState(self, weak_model=True)
             if st.runner is None:
                 return None
-            _LAST_PRIVATE = weakref.ref(st)
         if not st.arena.intact():                       # (p.data = ... of a different tensor: the epoch boundary)
             st.build_paths()
         return st

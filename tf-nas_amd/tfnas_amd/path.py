@@ -108,8 +108,7 @@ class _Slot:
 
 class PathRunner:
     def __init__(self, model, weights=None):
-        self.model = model
-        self.lib = _lib.lib()
+        self.lib = _lib.lib()                       # (no reference to the model itself: cells / stages are enough)
         self.cells = model.cells()
         self.stages = model.stages()
         self.weights = weights                      # WeightArena or None (then need_wgrad paths are refused)
@@ -134,6 +133,9 @@ class PathRunner:
     def close(self):
         for s in self._slots.values():
             self.lib.tfnas_path_destroy(s.ctx)
+            s.ctx = None                            # a backward that still holds this slot must raise (_check_gen), not pass
+            s.gen += 1                              # a freed context to tfnas_paths_bwd
+            s.arena = None
         self._slots = {}
 
     def __del__(self):
@@ -315,6 +317,9 @@ def _out_tensor(s, N, dev):
 
 
 def _check_gen(s, gen):
+    if s.ctx is None:
+        raise RuntimeError('tfnas_amd: the path-level state of this forward was released (Network.close() / SearchState.release() '
+                           '/ the model was rebuilt) before its backward ran')
     if s.gen != gen:
         raise RuntimeError('tfnas_amd: the path arena was overwritten by a later forward of the same slot before this '
                            'backward ran; run backward first or use the per-cell route (model(x, sampling, mode))')

@@ -16,6 +16,8 @@ import random
 
 import numpy as np
 
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,8 +45,12 @@ def make_optimizers(model, w_lr=0.025, w_mom=0.9, w_wd=1e-5, a_lr=0.01, a_wd=5e-
 class SearchState:
     """Caches the parameter lists the reference rebuilds from named_parameters() six times per step."""
 
-    def __init__(self, model):
-        self.model = model
+    def __init__(self, model, weak_model=False):
+        # weak_model: the state lives IN the model (Network._path_state keeps it as model._pstate) and must not keep the model
+        # alive: with a strong reference the two form a cycle that only the cyclic collector frees, and releasing "the previous
+        # model's state" by hand (rounds 3-4) pulled the path contexts out from under a model that was still in use
+        self._model_strong = None if weak_model else model
+        self._model_weak = weakref.ref(model) if weak_model else None
         self.weights = model.weight_parameters()
         self.arch = model.arch_parameters()
         self._mode = None
@@ -95,6 +101,16 @@ class SearchState:
         # the drop-in Network.forward (model_search.Network._path_state) runs on THIS state instead of building a second
         # arena that would fight over the parameters' storages
         self.model.__dict__['_pstate'] = self
+
+    @property
+    def model(self):
+        return self._model_strong if self._model_weak is None else self._model_weak()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def release(self):
         """Drop the path contexts / arenas and the back-reference the model holds (breaks the model <-> state cycle)."""
