@@ -14,7 +14,8 @@
  *    scratch; sizes come from tfnas_cell_ws();
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *  - return value: 0 ok, <0 invalid argument (TFNAS_E*), >0 a hipError_t;
- *  - re-entrant per stream.  The only process-global state is a registry of library-owned side streams (one per
+ *  - re-entrant per stream; every mode a launch runs in can be given in its descriptor (gemm_mode, flags, sync_fn).  The only
+ *    process-global state is the DEFAULTS of those modes (tfnas_set_gemm_mode / _lazy_join / _stats_sync), a registry of library-owned side streams (one per
  *    caller stream and device, created on first use by tfnas_mixedop_bwd with need_wgrad; released by
  *    tfnas_shutdown()) and the opt-in tfnas_prof_* timers; results never depend on either.
  *
@@ -34,7 +35,8 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): tfnas_fx_supported (fused per-image route of the late cells).
+/* 3 (round 5): tfnas_fx_supported (fused per-image route of the late cells); per-launch modes in TfnasCellDesc (gemm_mode, flags,
+ * sync_fn / sync_user / sync_world: the process-wide setters only provide defaults).
  * 2 (round 4): arithmetic modes of the GEMMs (tfnas_set_gemm_mode); the per-group input / output mode of TfnasCellDesc (xg /
  * og), TfnasPathDesc.dual, tfnas_path_set_side_stream2 and tfnas_path_defer_join / tfnas_path_join were measured and removed */
 #define TFNAS_ABI_VERSION 3
@@ -94,9 +96,20 @@ typedef struct TfnasCellDesc {
     int32_t stor;             /* must be 0 (fp32 storage of the [pixels][M] stream tensors E, D, dZ, dEh).  Rounds 1-3 had a
                                  second build that kept these four tensors in bf16 (stor = 1); it measured 0.99-1.04x of the
                                  fp32 iteration pair (the step is not bound by HBM bytes) and was removed.          [in] */
-    int32_t reserved0, reserved1;   /* must be 0 (ABI 1: xg / og, the per-group input / output mode of the removed dual paths) */
+    int32_t gemm_mode;        /* 0: the process default (tfnas_set_gemm_mode); TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_*: the arithmetic
+                                 of THIS launch's 1x1 GEMMs, whatever the default is (two models in one process in different
+                                 modes: an fp32-exact search net beside a bf16-GEMM derived net)                      [in] */
+    int32_t flags;            /* TFNAS_CELL_LAZY_JOIN: tfnas_mbconv_bwd returns without joining its weight-gradient side
+                                 stream (see tfnas_set_lazy_join, which sets the default for descriptors without the bit) [in] */
     TfnasGroup g[TFNAS_MAX_GROUPS];
+    /* per-launch cross-rank statistics hook (see tfnas_set_stats_sync: that one is the default for descriptors with
+       sync_fn == NULL); sync_world >= 1 */
+    int (*sync_fn)(void *user, double *table, uint64_t ndoubles, void *stream);
+    void *sync_user;
+    int32_t sync_world, pad_sync;
 } TfnasCellDesc;
+#define TFNAS_GEMM_EXPLICIT 0x1000
+#define TFNAS_CELL_LAZY_JOIN 1
 
 /* Element counts / offsets of every caller-allocated buffer of one cell. */
 typedef struct TfnasCellWs {

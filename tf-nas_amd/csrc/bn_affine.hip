@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void k_rowscale(float* __restrict__ out, const
 }
 
 int launch_bn_fwd_fix(double* stats, int nch, uint64_t cnt, float eps, const float* gamma, const float* beta, float* rmean,
-                      float* rvar, float momentum, int eval, hipStream_t s) {
+                      float* rvar, float momentum, int eval, hipStream_t s, uint64_t world) {
     if (nch <= 0) return 0;
     ProfScope _prof(TK_SMALL, s);
-    const uint64_t gcnt = cnt * stats_world();          // sync-stats: the statistics are those of the global batch
+    const uint64_t gcnt = cnt * world;                  // sync-stats: the statistics are those of the global batch
     const double unbias = gcnt > 1 ? (double)gcnt / (double)(gcnt - 1) : 1.0;
     hipLaunchKernelGGL(k_bn_fwd_fix, dim3(cdiv(nch, 256)), dim3(256), 0, s, stats, nch, 1.0 / (double)cnt, unbias, eps, gamma,
                        beta, rmean, rvar, momentum, eval);

@@ -164,7 +164,12 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
     if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
     if (d->has_res && (d->ic != d->oc || d->stride != 1)) return TFNAS_EINVAL;
-    if (d->reserved0 != 0 || d->reserved1 != 0) return TFNAS_EINVAL;   // (were xg / og: per-group inputs / outputs, removed)
+    if (d->gemm_mode != 0) {
+        const int gm = d->gemm_mode & ~(TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_EVERYWHERE);
+        if (!(d->gemm_mode & TFNAS_GEMM_EXPLICIT) || (gm != 0 && gm != 1 && gm != 3 && gm != 6)) return TFNAS_EINVAL;
+    }
+    if (d->flags & ~TFNAS_CELL_LAZY_JOIN) return TFNAS_EINVAL;
+    if (d->sync_fn && d->sync_world < 1) return TFNAS_ERANGE;
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
     d->Wo = (d->W - 1) / d->stride + 1;
@@ -258,7 +263,7 @@ static int bn_fwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     uint64_t cnt;
     bn_site(d, site, nch, cnt);
     return launch_bn_fwd_fix(stats, nch, cnt, d.eps, bn->weight[site], bn->bias[site], bn->running_mean[site],
-                             bn->running_var[site], bn->momentum, bn->eval, s);     // (sync-stats: kernels.h stats_world)
+                             bn->running_var[site], bn->momentum, bn->eval, s, stats_world(d));   // (sync-stats: global batch)
 }
 
 int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdBufs& b, hipStream_t s) {
@@ -281,16 +286,16 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
     else if (b.E) TRY(launch_expand_fwd(d, b.x, b.E, stats1, b.part, s));     // 1x1 expand (all groups) + BN1 statistics
     else TRY(launch_expand_stats_gram(d, b.x, stats1, b.part, s));            // E-free: BN1 statistics from the Gram matrix of x
     const bool sync = !(bn && bn->eval);          // (eval mode normalises with the running statistics: nothing to reduce)
-    if (sync) TRY(stats_sync(stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
+    if (sync) TRY(stats_sync(d, stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
     if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
     if (fx) TRY(launch_fx_fwd(d, b.x, stats1, b.E, b.D, stats2, b.part, s));  // expand + BN1 + act + depthwise in one kernel
     else TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));     // BN1+act fused load, depthwise, BN2 statistics
-    if (sync) TRY(stats_sync(stats2, 2 * (size_t)d.M, s));
+    if (sync) TRY(stats_sync(d, stats2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));
     TRY(launch_se_pool(d, b.D, stats2, pooled, s));                           // SE squeeze (SE groups only)
     TRY(launch_se_fc_fwd(d, pooled, hpre, gate, b.part, TFNAS_PART_FLOATS, s));    // SE excite (K-split partials in `part`)
     TRY(launch_project_fwd(d, b.D, gate, stats2, b.Pr, stats3, b.part, s));   // BN2+act+gate fused load, 1x1 project, BN3 stats
-    if (sync) TRY(stats_sync(stats3, 2 * (size_t)d.G * d.oc, s));
+    if (sync) TRY(stats_sync(d, stats3, 2 * (size_t)d.G * d.oc, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 2, stats3, s));
     if (b.drop_scale && d.has_res) {
         // drop-connect (tools/utils.py:77-86): out = scale[n] * BN3(.) + x -- the mix kernel without its residual, then one pass
@@ -365,7 +370,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         }
     }
     TRY(launch_mix_bwd_stats(d, b.dout, b.Pr, stats3, b.x, red3, part, s));           // BN3 backward sums (+ d wmix)
-    TRY(stats_sync(red3, 2 * (size_t)d.G * d.oc, s));
+    TRY(stats_sync(d, red3, 2 * (size_t)d.G * d.oc, s));
     if (b.dwmix) TRY(launch_mix_dw(d, red3, b.red + ws.off_resdot, b.dwmix, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 2, red3, s));
     // Nothing upstream wants a gradient (first cell of the alpha-step: frozen weights, input = stem output):
@@ -393,7 +398,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     TRY(launch_se_fc_bwd(d, dgate, gate, hpre, dgl, dhpre, dpooled, b.dEh, (size_t)ws.dEh, s));
     if (fused2) TRY(launch_bn2_finish(d, part, gate, dpooled, red2, s));      // BN2 backward sums
     else TRY(launch_bn2_bwd(d, b.dZ, b.D, stats2, gate, dpooled, red2, part, s));
-    TRY(stats_sync(red2, 2 * (size_t)d.M, s));
+    TRY(stats_sync(d, red2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_bwd_fix(d0, bn, 1, red2, s));
     if (!bn && fx_supported(d)) {
         // fused per-image route: depthwise dgrad + act' + the dE (rstd . W1) term of the expand dgrad in one kernel (dE never
@@ -420,10 +425,10 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         }
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
-    if (bn || stats_sync_on()) {
+    if (bn || stats_sync_on(d)) {
         // (unfused: the reduction that also builds cb1 would use the sums before the affine fix / the cross-rank reduction)
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, nullptr, dw_fused));
-        TRY(stats_sync(red1, 2 * (size_t)d.M, s));
+        TRY(stats_sync(d, red1, 2 * (size_t)d.M, s));
         if (bn) TRY(bn_bwd_fix(d0, bn, 0, red1, s));
         TRY(launch_bn1_consts(d, stats1, red1, cb1, s));
     } else {
@@ -519,7 +524,7 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
     b.drop_scale = drop_scale;
     b.dout_s = dout_s;
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
-    if (g_lazy_join) {              // the caller joins later (tfnas_side_join)
+    if (g_lazy_join || (d.flags & TFNAS_CELL_LAZY_JOIN)) {              // the caller joins later (tfnas_side_join)
         guard.joined = true;
         return 0;
     }
@@ -535,9 +540,9 @@ extern "C" int tfnas_head_affine_fwd(const TfnasCellDesc* dp, const TfnasBnAffin
     TfnasCellDesc d = d0;
     d.eps = -1.f;
     TRY(launch_expand_fwd(d, x, E, stats, part, s));
-    TRY(stats_sync(stats, 2 * (size_t)d.M, s));
+    TRY(stats_sync(d, stats, 2 * (size_t)d.M, s));
     TRY(launch_bn_fwd_fix(stats, d0.g[0].mc, (uint64_t)d0.N * d0.H * d0.W, d0.eps, bn->weight[0], bn->bias[0],
-                          bn->running_mean[0], bn->running_var[0], bn->momentum, bn->eval, s));
+                          bn->running_mean[0], bn->running_var[0], bn->momentum, bn->eval, s, stats_world(d0)));
     TRY(launch_head_pool(d, E, stats, pooled, s));
     return 0;
 }
@@ -554,7 +559,7 @@ extern "C" int tfnas_head_affine_bwd(const TfnasCellDesc* dp, const TfnasBnAffin
     d.eps = -1.f;
     const uint64_t cnt = (uint64_t)d0.N * d0.H * d0.W;
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));
-    TRY(stats_sync(red, 2 * (size_t)d.M, s));
+    TRY(stats_sync(d, red, 2 * (size_t)d.M, s));
     TRY(launch_bn_bwd_fix(red, d0.g[0].mc, cnt, bn->weight[0], bn->bias[0], bn->g_weight[0], bn->g_bias[0], s));
     if (bn->eval) HIP_TRY(hipMemsetAsync(red, 0, sizeof(double) * 2 * (size_t)d0.g[0].mc, s));
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
@@ -572,7 +577,7 @@ extern "C" int tfnas_head_fwd(const TfnasCellDesc* dp, const float* x, float* E,
     if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
     hipStream_t s = S(stream);
     TRY(launch_expand_fwd(d, x, E, stats, part, s));          // 1x1 conv 320->1280 + BN statistics
-    TRY(stats_sync(stats, 2 * (size_t)d.M, s));
+    TRY(stats_sync(d, stats, 2 * (size_t)d.M, s));
     TRY(launch_head_pool(d, E, stats, pooled, s));            // BN + swish + global average pool
     return 0;
 }
@@ -586,7 +591,7 @@ extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const flo
     if (d.need_wgrad && !d.g[0].g_expand) return TFNAS_ENULL;
     hipStream_t s = S(stream);
     TRY(launch_head_bwd(d, E, stats, dpooled, dEh, red, part, s));       // pool + swish backward, BN-backward sums
-    TRY(stats_sync(red, 2 * (size_t)d.M, s));
+    TRY(stats_sync(d, red, 2 * (size_t)d.M, s));
     TRY(launch_bn1_consts(d, stats, red, cb1, s));
     float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
     TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_stats1_gram(TfnasCellDesc d, const doub
 bool efree_supported(const TfnasCellDesc& d) {
     if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
     if (!efree_ic_ok(d.ic)) return fx_supported(d);            // late cells: the fused per-image route (fx_kernels.hip)
-    if (stats_sync_on()) return false;          // (cross-rank statistics are reduced on the (sum, sumsq) tables of E)
+    if (stats_sync_on(d)) return false;          // (cross-rank statistics are reduced on the (sum, sumsq) tables of E)
     if ((size_t)d.N * d.H * d.W * d.ic >= ((size_t)1 << 31)) return false;
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].k != 3 && d.g[g].k != 5) return false;

@@ -38,7 +38,7 @@ static int fx_ks(int ic) { return (ic + 31) / 32; }
 
 bool fx_plan(const TfnasCellDesc& d, FxPlan& pl, bool bwd) {
     if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
-    if (stats_sync_on()) return false;                     // (BN1 statistics come from the Gram matrix of x: efree_kernels.hip)
+    if (stats_sync_on(d)) return false;                     // (BN1 statistics come from the Gram matrix of x: efree_kernels.hip)
     if (d.ic < 64 || d.ic > 192 || (d.ic & 15)) return false;
     if (d.stride != 1) return false;                       // (stride-2 cells keep the materialised route)
     const int HW = d.H * d.W;

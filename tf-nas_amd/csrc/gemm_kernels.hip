@@ -1092,10 +1092,15 @@ int gemm_mode();
 static inline int gemm_slots(int nt, int mode = -1) { return 256 * gemm_lb(nt, mode < 0 ? gemm_mode() : mode); }
 // ragged mid widths (mc % 4 != 0 after the elasticity re-masking): the split-bf16 instantiations only have the aligned weight
 // loaders (the guarded ones cost ~50 registers, i.e. a resident workgroup), such launches keep the fp32 loop
+// the launch's arithmetic: the descriptor's own mode (TFNAS_GEMM_EXPLICIT) or the process default
 static inline int gemm_mode_for(const TfnasCellDesc& d) {
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].mc & 3) return 0;
+    if (d.gemm_mode & TFNAS_GEMM_EXPLICIT) return d.gemm_mode & 7;
     return gemm_mode();
+}
+static inline bool gemm_everywhere(const TfnasCellDesc& d) {
+    return (d.gemm_mode & TFNAS_GEMM_EXPLICIT) ? (d.gemm_mode & TFNAS_GEMM_EVERYWHERE) != 0 : g_gemm_everywhere != 0;
 }
 // The data-gradient GEMMs gain little from the bf16 pipe (their K loops are bound by the BN3-backward transform / the chunk ->
 // group bookkeeping and, with one candidate or large images, by bytes): measured per cell at B = 128 (tools/r4_cf.sh), split-bf16
@@ -1103,7 +1108,7 @@ static inline int gemm_mode_for(const TfnasCellDesc& d) {
 // They keep the fp32 loop except where they won.
 static inline int gemm_mode_dgrad(const TfnasCellDesc& d) {
     const int m = gemm_mode_for(d);
-    if (m == 0 || g_gemm_everywhere) return m;
+    if (m == 0 || gemm_everywhere(d)) return m;
     if (m == 1) return m;                                  // plain bf16 is a reduced-precision MODE, not a policy: everywhere
     return (d.G > 1 && d.Ho * d.Wo <= 196) ? m : 0;
 }

@@ -10,12 +10,20 @@ struct StatsSync {
     void* user;
     int world;
 };
-extern StatsSync g_stats_sync;
-static inline bool stats_sync_on() { return g_stats_sync.fn != nullptr; }
-static inline int stats_sync(double* table, size_t ndoubles, hipStream_t s) {
-    return g_stats_sync.fn ? g_stats_sync.fn(g_stats_sync.user, table, (uint64_t)ndoubles, (void*)s) : 0;
+extern StatsSync g_stats_sync;              // the process default (tfnas_set_stats_sync); a descriptor's own hook wins
+static inline StatsSync sync_of(const TfnasCellDesc& d) {
+    if (d.sync_fn) return StatsSync{d.sync_fn, d.sync_user, d.sync_world > 0 ? d.sync_world : 1};
+    return g_stats_sync;
 }
-static inline uint64_t stats_world() { return (g_stats_sync.fn && g_stats_sync.world > 1) ? (uint64_t)g_stats_sync.world : 1; }
+static inline bool stats_sync_on(const TfnasCellDesc& d) { return sync_of(d).fn != nullptr; }
+static inline int stats_sync(const TfnasCellDesc& d, double* table, size_t ndoubles, hipStream_t s) {
+    const StatsSync y = sync_of(d);
+    return y.fn ? y.fn(y.user, table, (uint64_t)ndoubles, (void*)s) : 0;
+}
+static inline uint64_t stats_world(const TfnasCellDesc& d) {
+    const StatsSync y = sync_of(d);
+    return (y.fn && y.world > 1) ? (uint64_t)y.world : 1;
+}
 
 // gemm_kernels.hip
 int gemm_mode();            // arithmetic of the row-tiled GEMMs (tfnas_hip.h: TFNAS_GEMM_*)
@@ -154,7 +162,7 @@ int launch_arch_adam_project(int n, float* const* p, const float* const* g, cons
 
 // bn_affine.hip (derived-network path: affine BatchNorm folded into the statistics tables, drop-connect)
 int launch_bn_fwd_fix(double* stats, int nch, uint64_t cnt, float eps, const float* gamma, const float* beta, float* rmean,
-                      float* rvar, float momentum, int eval, hipStream_t s);
+                      float* rvar, float momentum, int eval, hipStream_t s, uint64_t world = 1);
 int launch_bn_bwd_fix(double* red, int nch, uint64_t cnt, const float* gamma, const float* beta, float* dgamma, float* dbeta,
                       hipStream_t s);
 int launch_rowscale(float* out, const float* y, const float* res, const float* scale, int N, uint64_t per_image,

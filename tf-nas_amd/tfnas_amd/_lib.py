@@ -22,6 +22,10 @@ _W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e
 _G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
 
 
+GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN = 0x1000, 0x100, 1
+GEMM_MODES = {'f32': 0, 'bf16': 1, 'x2': 3, 'x3': 6}
+
+
 class TfnasGroup(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('mc', 'k', 'se', 'mcp', 'off', 'se_off', 'pad0', 'pad1')]
                 + [(n, C.c_void_p) for n in _W_FIELDS] + [(n, C.c_void_p) for n in _G_FIELDS])
@@ -31,7 +35,8 @@ class TfnasCellDesc(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'H', 'W', 'ic', 'oc', 'stride', 'act', 'has_res', 'G', 'need_wgrad',
                                           'Ho', 'Wo', 'M', 'SE')]
                 + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
-                   ('stor', C.c_int32), ('reserved0', C.c_int32), ('reserved1', C.c_int32), ('g', TfnasGroup * MAX_GROUPS)])
+                   ('stor', C.c_int32), ('gemm_mode', C.c_int32), ('flags', C.c_int32), ('g', TfnasGroup * MAX_GROUPS),
+                   ('sync_fn', C.c_void_p), ('sync_user', C.c_void_p), ('sync_world', C.c_int32), ('pad_sync', C.c_int32)])
 
 
 class TfnasCellWs(C.Structure):

@@ -76,6 +76,40 @@ def _no_plan():
     return None
 
 
+class HipModes:
+    """Launch modes of ONE model (TfnasCellDesc.gemm_mode / flags / sync_*: include/tfnas_hip.h) -- every descriptor a model's
+    plans hand to the library carries them, so two models in one process can run in different modes (an fp32-exact search net, a
+    bf16-GEMM derived net, an EMA copy ...).  ``None`` / False = the library's process-wide default (tfnas_set_gemm_mode,
+    tfnas_set_lazy_join, tfnas_set_stats_sync).
+      gemm         None | 'x3' | 'f32' | 'x2' | 'bf16'   arithmetic of the 1x1 GEMMs;  everywhere: no per-launch shape policy
+      lazy_join    tfnas_mbconv_bwd leaves its weight-gradient kernels on the side stream (RetrainState joins once per step)
+      direct_grads the derived network's blocks write weight gradients straight into the .grad views (host-side only)
+      sync         None | (function pointer, user pointer, world): cross-rank BatchNorm statistics hook of this model"""
+
+    def __init__(self, gemm=None, everywhere=False, lazy_join=False, direct_grads=False, sync=None):
+        self.gemm, self.everywhere, self.lazy_join, self.direct_grads, self.sync = gemm, everywhere, lazy_join, direct_grads, sync
+
+    def apply(self, d):
+        d.gemm_mode = 0 if self.gemm is None else (_lib.GEMM_EXPLICIT | _lib.GEMM_MODES[self.gemm]
+                                                   | (_lib.GEMM_EVERYWHERE if self.everywhere else 0))
+        d.flags = _lib.CELL_LAZY_JOIN if self.lazy_join else 0
+        if self.sync is None:
+            d.sync_fn, d.sync_user, d.sync_world = None, None, 0
+        else:
+            d.sync_fn, d.sync_user, d.sync_world = self.sync[0], self.sync[1], int(self.sync[2])
+
+
+DEFAULT_MODES = HipModes()         # plans of modules that belong to no model with its own modes (the library defaults)
+
+
+def adopt_modes(root, modes=None):
+    """Give every sub-module of ``root`` the same HipModes object (``root.hip_modes``); plans look it up through their blocks."""
+    modes = modes if modes is not None else HipModes()
+    for m in root.modules():
+        object.__setattr__(m, 'hip_modes', modes)
+    return modes
+
+
 class CellPlan:
     """Host-side description of one MixedOP launch: geometry + which candidate blocks take part.
 
@@ -88,9 +122,10 @@ class CellPlan:
     def __deepcopy__(self, memo):
         return None
 
-    def __init__(self, ic, oc, stride, act, blocks, mode=_lib.MODE_CELL):
+    def __init__(self, ic, oc, stride, act, blocks, mode=_lib.MODE_CELL, modes=None):
         self.ic, self.oc, self.stride, self.act = ic, oc, stride, act
         self.blocks = list(blocks)                     # MBInvertedResBlock modules (parameter containers)
+        self._modes = modes
         self.mode = mode
         self.has_res = int(mode == _lib.MODE_CELL and ic == oc and stride == 1)
         self._desc_cache = {}
@@ -100,6 +135,12 @@ class CellPlan:
         for b in self.blocks:
             ps.extend(b.hip_params())
         return ps
+
+    @property
+    def modes(self):
+        """The owning model's HipModes (looked up through the first block at every launch: a model may change them)."""
+        m = self._modes if self._modes is not None else getattr(self.blocks[0], 'hip_modes', None)
+        return m if m is not None else DEFAULT_MODES
 
     def desc(self, N, H, W):
         key = (N, H, W)
@@ -118,6 +159,7 @@ class CellPlan:
             check(_lib.lib().tfnas_cell_ws(C.byref(d), C.byref(ws)), 'tfnas_cell_ws')
             hit = (d, ws)
             self._desc_cache[key] = hit
+        self.modes.apply(hit[0])                       # (every launch: the descriptor is cached, the model's modes may change)
         return hit
 
     def bind(self, d, params, grads=None):
@@ -442,13 +484,15 @@ def _bn_struct(bns, training, grads=None):
 #           (no temporaries, no AccumulateGrad add per parameter: ~200 tiny launches per step);
 #   lazy:   tfnas_mbconv_bwd leaves the weight-gradient kernels on the side stream (tfnas_set_lazy_join); the tensors they read
 #           are handed to the caching allocator with record_stream(side), the step joins once before the optimizer kernel.
-_RETRAIN = {'direct': False, 'lazy': False}
 _side_streams = {}
 
 
-def retrain_context(direct, lazy):
-    _RETRAIN['direct'], _RETRAIN['lazy'] = bool(direct), bool(lazy)
-    _lib.lib().tfnas_set_lazy_join(int(bool(lazy)))
+def retrain_context(direct, lazy, model=None):
+    """Switch the in-place gradient / lazy-join route of a derived network's training step on or off: for ``model`` (its
+    HipModes; model_eval.RetrainState does this around every step), or -- without a model -- for the plans of modules that belong
+    to no model with modes of its own (DEFAULT_MODES).  Nothing process-global changes in the library."""
+    m = DEFAULT_MODES if model is None else model.hip_modes
+    m.direct_grads, m.lazy_join = bool(direct), bool(lazy)
 
 
 def _side_stream(dev):
@@ -469,9 +513,9 @@ def retrain_join(dev):
         check(_lib.lib().tfnas_side_join(_stream(dev)), 'tfnas_side_join')
 
 
-def _direct_targets(params):
+def _direct_targets(params, modes):
     """The .grad views to write into, or None when a parameter has no (contiguous fp32) .grad yet."""
-    if not _RETRAIN['direct']:
+    if not modes.direct_grads:
         return None
     out = []
     for p in params:
@@ -518,7 +562,7 @@ class MBConvAffineFn(torch.autograd.Function):
                 if m is not None and m.num_batches_tracked is not None:
                     m.num_batches_tracked += 1
         ctx.plan, ctx.shape, ctx.bns, ctx.training, ctx.n_conv = plan, (N, H, W), bns, training, n_conv
-        ctx.direct = _direct_targets(params) if training else None
+        ctx.direct = _direct_targets(params, plan.modes) if training else None
         ctx.save_for_backward(xh, ds, E, D, Pr, fsmall, stats, *params)
         return out.permute(0, 3, 1, 2)
 
@@ -553,9 +597,9 @@ class MBConvAffineFn(torch.autograd.Function):
                                               ptr(stats), ptr(douth), ptr(dout_s), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
                                               ptr(part), ptr(dx), ptr(dxp), _stream(dev)), 'tfnas_mbconv_bwd')
         d.need_wgrad = 0
-        if _RETRAIN['lazy'] and direct is None:
+        if plan.modes.lazy_join and direct is None:
             retrain_join(dev)               # gradient temporaries go back to autograd: they must be complete on this stream
-        elif _RETRAIN['lazy']:
+        elif plan.modes.lazy_join:
             side = _side_stream(dev)
             if side is not None:            # the weight-gradient kernels still read these when this function returns
                 for t in (xh, ds, E, D, Pr, fsmall, stats, douth, dout_s, dZ, dEh, bsmall, red, part):

@@ -50,6 +50,15 @@ class _DerivedBase(nn.Module):
         self.classifier = LinearLayer(1280, num_classes)
         self._initialization()
         self._stem_plan = self._head_plan = None
+        from .functions import adopt_modes
+        adopt_modes(self)                      # self.hip_modes (functions.HipModes), shared by every sub-module's plans
+
+    def set_hip_modes(self, **kw):
+        """e.g. set_hip_modes(gemm='bf16'): this model's launches only (TfnasCellDesc.gemm_mode; functions.HipModes)."""
+        for k, v in kw.items():
+            if not hasattr(self.hip_modes, k):
+                raise AttributeError(k)
+            setattr(self.hip_modes, k, v)
 
     def _stages(self):
         return [getattr(self, 'stage%d' % i) for i in range(1, 7)]
@@ -57,7 +66,7 @@ class _DerivedBase(nn.Module):
     def _stem(self, x):
         fs, ss = self.first_stem, self.second_stem
         if self._stem_plan is None:
-            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [_StemBlock(fs, ss)], mode=_lib.MODE_STEM)
+            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [_StemBlock(fs, ss)], mode=_lib.MODE_STEM, modes=self.hip_modes)
         plan = self._stem_plan
         bns = [fs.bn, ss.depth_conv.bn, ss.point_linear.bn]
         conv = plan.params()
@@ -67,7 +76,7 @@ class _DerivedBase(nn.Module):
     def _head(self, x):
         fm = self.feature_mix_layer
         if self._head_plan is None:
-            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [_HeadBlock(fm)], mode=_lib.MODE_HEAD)
+            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [_HeadBlock(fm)], mode=_lib.MODE_HEAD, modes=self.hip_modes)
         return HeadAffineFn.apply(self._head_plan, x, fm.bn, self.training, fm.conv.weight, fm.bn.weight, fm.bn.bias)
 
     def forward(self, x):
@@ -259,14 +268,14 @@ class RetrainState:
         for p in a.params:
             if p.grad is None or p.grad.data_ptr() != a.grad_ptr(p):
                 p.grad = a.grad_view(p)
-        functions.retrain_context(DIRECT_GRADS, LAZY_JOIN)
+        functions.retrain_context(DIRECT_GRADS, LAZY_JOIN, self.model)
 
     def end(self):
         """Join the weight-gradient stream and leave the training-step context (also on an error path)."""
         from . import functions
-        if functions._RETRAIN['lazy']:
+        if self.model.hip_modes.lazy_join:
             functions.retrain_join(self.arena.device)
-        functions.retrain_context(False, False)
+        functions.retrain_context(False, False, self.model)
 
     def step(self, opt, grad_clip, group=None):
         import ctypes as C

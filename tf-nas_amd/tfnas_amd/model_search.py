@@ -241,6 +241,15 @@ class Network(nn.Module):
         self._lat_stack = None
         self._stem_plan = None
         self._head_plan = None
+        from .functions import adopt_modes
+        adopt_modes(self)                      # self.hip_modes (functions.HipModes), shared by every sub-module's plans
+
+    def set_hip_modes(self, **kw):
+        """e.g. set_hip_modes(gemm='f32'): this model's launches only (TfnasCellDesc.gemm_mode; functions.HipModes)."""
+        for k, v in kw.items():
+            if not hasattr(self.hip_modes, k):
+                raise AttributeError(k)
+            setattr(self.hip_modes, k, v)
 
     # ---- stems / head on the HIP path -------------------------------------------------------------------
     class _StemBlock:
@@ -269,14 +278,14 @@ class Network(nn.Module):
                 or ss.inverted_bottleneck is not None or ss.squeeze_excite is None:
             raise NotImplementedError('stem geometry differs from models/model_search.py:219-220')
         if self._stem_plan is None:
-            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [Network._StemBlock(fs, ss)], mode=_lib.MODE_STEM)
+            self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [Network._StemBlock(fs, ss)], mode=_lib.MODE_STEM, modes=self.hip_modes)
         plan = self._stem_plan
         return StemFn.apply(plan, x, None, *plan.params())
 
     def _head(self, x):
         fm = self.feature_mix_layer
         if self._head_plan is None:
-            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [Network._HeadBlock(fm)], mode=_lib.MODE_HEAD)
+            self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [Network._HeadBlock(fm)], mode=_lib.MODE_HEAD, modes=self.hip_modes)
         return HeadFn.apply(self._head_plan, x, fm.conv.weight)
 
     def stages(self):

@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from ._lib import TfnasCellDesc, TfnasPathDesc, TfnasPathWs, check, ptr, raw_array
-from .functions import BN_EPS, EFREE, EFREE_STRIDE1, _nhwc, _on, _require_cuda
+from .functions import BN_EPS, DEFAULT_MODES, EFREE, EFREE_STRIDE1, _nhwc, _on, _require_cuda
 
 ALIGN = 64          # floats; every parameter starts on a 256-byte boundary of the arenas
 
@@ -152,6 +152,7 @@ class PathRunner:
         blocks = list(cell.m_ops) if idx is None else [cell.m_ops[idx]]
         t = self._tmpl.get(key)
         if t is not None and t.g[0].w_expand == blocks[0].inverted_bottleneck.conv.weight.data_ptr():
+            getattr(cell, 'hip_modes', DEFAULT_MODES).apply(t)          # (the model's launch modes may have changed)
             return t
         d = TfnasCellDesc()
         d.N, d.H, d.W, d.ic, d.oc, d.stride = N, H, W, cell.in_channels, cell.out_channels, cell.stride
@@ -170,6 +171,7 @@ class PathRunner:
             if self.weights is not None and all(self.weights.owns(p) for p in ps):
                 for j, f in enumerate(_lib._G_FIELDS[:len(ps)]):
                     setattr(d.g[g], f, self.weights.grad_ptr(ps[j]))
+        getattr(cell, 'hip_modes', DEFAULT_MODES).apply(d)
         check(self.lib.tfnas_cell_plan(C.byref(d)), 'tfnas_cell_plan')
         self._tmpl[key] = d
         return d

@@ -38,9 +38,12 @@ def _libs():
     return [_lib.lib()]
 
 
-def enable(group=None):
+def enable(group=None, model=None):
     """Install the hook for ``group`` (default: WORLD).  No-op without an initialised process group or at world size 1
-    unless tfnas_amd.search.FORCE_ALLREDUCE_AT_WORLD_1 is set (tests)."""
+    unless tfnas_amd.search.FORCE_ALLREDUCE_AT_WORLD_1 is set (tests).
+    model: only this model's launches reduce their statistics (its descriptors carry the hook: TfnasCellDesc.sync_fn, via
+    model.hip_modes.sync); without a model the hook becomes the process default (tfnas_set_stats_sync) for every launch whose
+    descriptor names none."""
     import torch.distributed as dist
     from . import search
     if not (dist.is_available() and dist.is_initialized()):
@@ -65,6 +68,11 @@ def enable(group=None):
             _STATE['error'] = e
             return -1000
     cb = _FN(hook)
+    if model is not None:
+        model.hip_modes.sync = (C.cast(cb, C.c_void_p).value, None, int(world))
+        _STATE.setdefault('model_cbs', []).append(cb)  # (keeps the ctypes thunk alive)
+        _STATE.update(group=group, world=world)
+        return True
     for l in _libs():
         _lib.check(l.tfnas_set_stats_sync(C.cast(cb, C.c_void_p), None, int(world)), 'tfnas_set_stats_sync')
     _STATE.update(cb=cb, group=group, world=world)     # (keeps the ctypes thunk alive)
