@@ -87,7 +87,20 @@ def family_algorithmic(fam, B, mode=None):
             HWo = Po // N
             folded = HWo >= 43 and (launches != 1 or HWo <= 784)
             rec_bytes = 4.0 * (Po / 128.0) * (1.0 + 128.0 / HWo) * 3.5 * M    # ~(5 + 2) / 2 sums per (row tile, image, channel)
-            if fam == 'k_expand_fwd' and efree:
+            # fused per-image route (csrc/fx_kernels.hip; tfnas_fx_supported): the alpha-step launches of the stride-1 cells at 14 x 14
+            # / 7 x 7 run expand + BN1 + act + depthwise in one kernel per direction (ehat kept in the E buffer for the backward, dE
+            # never formed: partial sums of dx per channel slice, ~8 slices); BN1 statistics from the Gram matrix of x
+            fx = launches == 1 and s == 1 and H * W <= 196 and 64 <= ic <= 192 and os.environ.get('TFNAS_FX', '1') != '0'
+            nsl = 8.0
+            if fam == 'k_expand_fwd' and fx:
+                f, b, kernels = 2.0 * P * ic * ic, 4.0 * (2 * P * ic), 2
+            elif fam == 'k_dw_fwd' and fx:
+                f, b, kernels = 2.0 * Po * M * 17.0 + 2.0 * P * ic * M, 4.0 * (P * ic + Po * M + P * M), 1
+            elif fam == 'k_dw_bwd_data' and fx:
+                f, b, kernels = 2.0 * P * M * 17.0 + 2.0 * P * M * ic, 4.0 * (2 * Po * M + P * M + nsl * P * ic), 1
+            elif fam == 'k_expand_dgrad' and fx:
+                f, b = 2.0 * P * ic * ic, 4.0 * ((nsl + 3) * P * ic)
+            elif fam == 'k_expand_fwd' and efree:
                 f, b, kernels = 2.0 * P * ic * ic, 4.0 * (2 * P * ic), 2
             elif fam == 'k_dw_fwd' and efree:
                 f, b = 2.0 * Po * M * 17.0 + 2.0 * P * ic * M, 4.0 * (P * ic + Po * M)

@@ -136,21 +136,28 @@ __global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, con
     unsigned char* b = blob + (size_t)chunk * pl.BLOB;
     const float* __restrict__ w1 = d.g[g].w_expand;
     __shared__ float2 cst[8];
+    __shared__ float w1s[8][200];                  // the octet's weight rows (ic <= 192; zeros for channels past mc)
     if (tid < 8) {
         float2 c = make_float2(0.f, 0.f);
         if (c0 + cy + tid < mc) c = bn_consts(stats1 + 2 * (size_t)(off + c0 + cy + tid), 1.0 / ((double)d.N * d.H * d.W), d.eps);
         cst[tid] = c;
         reinterpret_cast<float2*>(b + 96 * RS)[cy + tid] = c;
     }
-    for (int e = tid; e < 8 * KP; e += 256) {
-        const int ch = cy + e / KP, k = e % KP;
-        const float v = (c0 + ch < mc && k < ic) ? w1[(size_t)(c0 + ch) * ic + k] : 0.f;
-        unsigned short h, m, l;
-        fx_split3(v, h, m, l);
-        unsigned short* row = reinterpret_cast<unsigned short*>(b + ch * RS) + k;
-        row[0] = h;
-        row[16 * RS] = m;            // (+ 32 rows of RS bytes = 16 RS shorts)
-        row[32 * RS] = l;
+    for (int e = tid; e < 8 * ic; e += 256) {
+        const int chl = e / ic, c = e - chl * ic;
+        w1s[chl][c] = (c0 + cy + chl < mc) ? w1[(size_t)(c0 + cy + chl) * ic + c] : 0.f;
+    }
+    __syncthreads();
+    // planes: 8 consecutive k of one channel per item -> one 16-byte store per plane
+    for (int e = tid; e < 8 * (KP / 8); e += 256) {
+        const int chl = e / (KP / 8), k0 = 8 * (e - chl * (KP / 8));
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fx_split3(k0 + j < ic ? w1s[chl][k0 + j] : 0.f, h[j], m[j], l[j]);
+        unsigned char* row = b + (cy + chl) * RS + 2 * k0;
+        *reinterpret_cast<u32x4*>(row) = u32x4{h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16};
+        *reinterpret_cast<u32x4*>(row + 32 * RS) = u32x4{m[0] | (unsigned)m[1] << 16, m[2] | (unsigned)m[3] << 16, m[4] | (unsigned)m[5] << 16, m[6] | (unsigned)m[7] << 16};
+        *reinterpret_cast<u32x4*>(row + 64 * RS) = u32x4{l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16};
     }
     float* taps = reinterpret_cast<float*>(b + pl.PB);
     for (int e = tid; e < KK * 8; e += 256) {
@@ -172,18 +179,16 @@ __global__ __launch_bounds__(256) void k_fx_pack(TfnasCellDesc d, FxPlan pl, con
             }
             c2[ch] = t;
         }
-        __syncthreads();
+        // Wr: the octet's 8 channels of input channel c are one 16-byte group of row c
         unsigned char* wr = b + pl.PB + pl.WB + 512;
-        for (int e = tid; e < 8 * ic; e += 256) {
-            const int chl = e / ic, c = e - chl * ic, ch = cy + chl;      // (reads of W1 rows stay coalesced)
-            const float v = (c0 + ch < mc) ? cst[chl].y * w1[(size_t)(c0 + ch) * ic + c] : 0.f;
-            unsigned short h, m, l;
-            fx_split3(v, h, m, l);
-            const int grp = (ch >> 3) ^ fx_swz(c);
-            unsigned short* p = reinterpret_cast<unsigned short*>(wr + c * 64 + grp * 16) + (ch & 7);
-            p[0] = h;
-            p[ic * 32] = m;          // plane stride ic * 64 bytes
-            p[ic * 64] = l;
+        for (int c = tid; c < ic; c += 256) {
+            unsigned short h[8], m[8], l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fx_split3(cst[j].y * w1s[j][c], h[j], m[j], l[j]);
+            unsigned char* p = wr + c * 64 + (((cy >> 3) ^ fx_swz(c)) * 16);
+            *reinterpret_cast<u32x4*>(p) = u32x4{h[0] | (unsigned)h[1] << 16, h[2] | (unsigned)h[3] << 16, h[4] | (unsigned)h[5] << 16, h[6] | (unsigned)h[7] << 16};
+            *reinterpret_cast<u32x4*>(p + ic * 64) = u32x4{m[0] | (unsigned)m[1] << 16, m[2] | (unsigned)m[3] << 16, m[4] | (unsigned)m[5] << 16, m[6] | (unsigned)m[7] << 16};
+            *reinterpret_cast<u32x4*>(p + 2 * ic * 64) = u32x4{l[0] | (unsigned)l[1] << 16, l[2] | (unsigned)l[3] << 16, l[4] | (unsigned)l[5] << 16, l[6] | (unsigned)l[7] << 16};
         }
     }
 }
@@ -1181,11 +1186,12 @@ __global__ __launch_bounds__(256) void k_fx_gram(const float* __restrict__ x, in
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-    // 16 rows per iteration: all their loads are issued before the first MFMA (one dependent L2 round trip per iteration, not four)
-    for (int p = r0; p < r1; p += 16) {
-        float a[4][NT], b[4][NT];
+    // 32 rows per iteration: all their loads are issued before the first MFMA (one dependent memory round trip per iteration)
+    constexpr int RU = 8;
+    for (int p = r0; p < r1; p += 4 * RU) {
+        float a[RU][NT], b[RU][NT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RU; ++u) {
             const int row = p + 4 * u + q;
             const float* __restrict__ xr = x + (size_t)(row < r1 ? row : r1 - 1) * ic + n;
 #pragma unroll
@@ -1197,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_fx_gram(const float* __restrict__ x, in
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -1233,45 +1239,50 @@ __device__ __forceinline__ const float* fx_wrow(const TfnasCellDesc& d, int col)
     return (m >= 0 && m < d.g[g].mc) ? d.g[g].w_expand + (size_t)m * d.ic : nullptr;
 }
 template <int CT>
-__global__ __launch_bounds__(64) void k_fx_stats1(TfnasCellDesc d, const double* __restrict__ xsum, const double* __restrict__ C,
-                                                  double* __restrict__ stats1) {
-    const int lane = threadIdx.x, n = lane & 15, q = lane >> 4, ic = d.ic, col0 = blockIdx.x * 16;
+__global__ __launch_bounds__(256) void k_fx_stats1(TfnasCellDesc d, const double* __restrict__ xsum, const double* __restrict__ C,
+                                                   double* __restrict__ stats1) {
+    // 4 waves per 16 channels: wave w owns the column tiles t = w, w + 4, .. of T (one wave alone is a chain of CT x ic / 4
+    // 64-cycle fp64 MFMAs with a quarter of a wave per SIMD on the chip); the q / s dot products are summed across waves in LDS
+    constexpr int NT = (CT + 3) / 4;
+    __shared__ double red[2][4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, ic = d.ic, col0 = blockIdx.x * 16;
     const float* __restrict__ wa = fx_wrow(d, col0 + n);                 // A operand: row n, k = q
-    f64x4 acc[CT];
+    f64x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     const float* __restrict__ wac = wa ? wa : d.g[0].w_expand;           // (always a valid address: the load is unconditional)
-    // operands of three k-steps in flight (the loop is a chain of L2 round trips otherwise: 48 steps x ~1.2 us at ic = 192)
-    constexpr int PD = 3;
+    int ctile[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ctile[t] = wave + 4 * t < CT ? 16 * (wave + 4 * t) : 0;
+    constexpr int PD = 4;
     float an[PD];
-    double bn[PD][CT];
+    double bn[PD][NT];
     const int nks = ic >> 2;
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
         const int k = 4 * (u < nks ? u : nks - 1) + q;
         an[u] = wac[k];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) bn[u][t] = C[(size_t)k * ic + n + 16 * t];
+        for (int t = 0; t < NT; ++t) bn[u][t] = C[(size_t)k * ic + n + ctile[t]];
     }
     for (int ks = 0; ks < nks; ks += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const bool live = ks + u < nks;                                 // (wave-uniform; a dead step multiplies by a = 0)
             const double a = (wa && live) ? (double)an[u] : 0.0;
-            double b[CT];
+            double b[NT];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) b[t] = bn[u][t];
+            for (int t = 0; t < NT; ++t) b[t] = bn[u][t];
             const int kn = ks + u + PD;
             const int k = 4 * (kn < nks ? kn : nks - 1) + q;
             an[u] = wac[k];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) bn[u][t] = C[(size_t)k * ic + n + 16 * t];
+            for (int t = 0; t < NT; ++t) bn[u][t] = C[(size_t)k * ic + n + ctile[t]];
 #pragma unroll
-            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
         }
     }
-    // acc[t][i] = T[row q + 4 i][column 16 t + n]
-    const double P = (double)d.N * d.H * d.W;
+    // acc[t][i] = T[row q + 4 i][column ctile[t] + n]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = col0 + q + 4 * i;
@@ -1279,10 +1290,12 @@ __global__ __launch_bounds__(64) void k_fx_stats1(TfnasCellDesc d, const double*
         double qf = 0.0, sm = 0.0;
         if (wr) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                const double wv = (double)wr[16 * t + n];
-                qf += acc[t][i] * wv;
-                sm += wv * xsum[16 * t + n];
+            for (int t = 0; t < NT; ++t) {
+                if (wave + 4 * t < CT) {
+                    const double wv = (double)wr[ctile[t] + n];
+                    qf += acc[t][i] * wv;
+                    sm += wv * xsum[ctile[t] + n];
+                }
             }
         }
 #pragma unroll
@@ -1290,10 +1303,18 @@ __global__ __launch_bounds__(64) void k_fx_stats1(TfnasCellDesc d, const double*
             qf += __shfl_xor(qf, o, 64);
             sm += __shfl_xor(sm, o, 64);
         }
-        if (n == 0 && col < d.M) {
-            stats1[2 * (size_t)col + 0] = sm;
-            stats1[2 * (size_t)col + 1] = qf + sm * sm / P;
+        if (n == 0) {
+            red[0][wave][q + 4 * i] = sm;
+            red[1][wave][q + 4 * i] = qf;
         }
+    }
+    __syncthreads();
+    if (tid < 16 && col0 + tid < d.M) {
+        const double sm = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+        const double qf = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+        const double P = (double)d.N * d.H * d.W;
+        stats1[2 * (size_t)(col0 + tid) + 0] = sm;
+        stats1[2 * (size_t)(col0 + tid) + 1] = qf + sm * sm / P;          // sum E^2 = centred sum of squares + P mean^2
     }
 }
 
@@ -1327,7 +1348,7 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
     if (rc) return rc;
     ProfScope _prof(TK_SMALL, s);
     switch (ic / 16) {
-#define FX_ST1(N_) case N_: hipLaunchKernelGGL(k_fx_stats1<N_>, dim3(cdiv(d.M, 16)), dim3(64), 0, s, d, xsum, Cm, stats1); break;
+#define FX_ST1(N_) case N_: hipLaunchKernelGGL(k_fx_stats1<N_>, dim3(cdiv(d.M, 16)), dim3(256), 0, s, d, xsum, Cm, stats1); break;
         FX_ST1(4) FX_ST1(5) FX_ST1(6) FX_ST1(7) FX_ST1(8) FX_ST1(9) FX_ST1(10) FX_ST1(11) FX_ST1(12)
 #undef FX_ST1
         default: return TFNAS_EINVAL;

@@ -26,6 +26,7 @@ def family(name):
     # kernels that share an event family (tfnas_prof / bench.py "kernel_ms_per_pair") with an older name
     fam = {'k_dws_fwd': 'k_dw_fwd', 'k_dws_bwd': 'k_dw_bwd_data', 'k_dws_wgrad': 'k_dw_wgrad',
            'k_dwd_fwd': 'k_dw_fwd', 'k_dwd_bwd': 'k_dw_bwd_data', 'k_dwd_wgrad': 'k_dw_wgrad',
+           'k_fx_fwd': 'k_dw_fwd', 'k_fx_bwde': 'k_dw_bwd_data', 'k_fx_bwd': 'k_dw_bwd_data',
            'k_bn2_finish': 'k_bn2_bwd'}.get(fam, fam)
     if fam in ('k_bn2_pool', 'k_bn2_gather'):
         return 'k_se_pool<bwd>'
