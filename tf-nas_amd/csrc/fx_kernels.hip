@@ -33,6 +33,22 @@
 #define FX_ABL 0
 #endif
 
+// -DFX_TIMING (tools/fx_timeline.py): shader-clock stamps of one chunk interval (FXT_CHUNK) of the first 64 workgroups, per wave
+#ifdef FX_TIMING
+#ifndef FXT_CHUNK
+#define FXT_CHUNK 3
+#endif
+__device__ unsigned long long g_fxt[64 * 8 * 16];
+#define FXT(chunk_, slot_)                                                                                   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && ((chunk_) == FXT_CHUNK || (chunk_) < 0))              \
+        g_fxt[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (slot_)] = __builtin_readcyclecounter();
+extern "C" int tfnas_dbg_fx_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fxt), sizeof(unsigned long long) * (size_t)n);
+}
+#else
+#define FXT(chunk_, slot_)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------- plan
 static int fx_ks(int ic) { return (ic + 31) / 32; }
 
@@ -544,7 +560,9 @@ __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan
                 const int o = (lane + 64 * u) * 16;
                 vw[u] = *reinterpret_cast<const u32x4*>(sw + (o < WBK ? o : WBK - 16));
             }
+            FXT(i, 0)
             __syncthreads();
+            FXT(i, 1)
             if (i > 0 && lane < 64) {                                      // statistics of chunk i - 1 -> this group's partial row
                 const int ch = lane & 31, which = lane >> 5, c0p = sl.c0 + 32 * (i - 1);
                 const float* st = St((i - 1) & 1);
@@ -582,6 +600,7 @@ __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan
                     if (o < WBK) *reinterpret_cast<u32x4*>(dw + o) = vw[u];
                 }
             }
+            FXT(i, 2)
         }
         __syncthreads();
         {
@@ -637,12 +656,15 @@ __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan
     for (int i = 0; i < nch; ++i) {
         // interval i: stencil of chunk i  ||  MFMAs of chunk i + 1  (the copier brings planes of chunk i + 2, taps of chunk i + 1)
         const bool w1 = i + 1 < nch;
+        FXT(i, 0)
         __syncthreads();
+        FXT(i, 1)
         const int c0 = sl.c0 + 32 * i;
         const bool chok = c0 + 4 * cq < mcp;
         // (the last interval runs the MFMAs on the stale planes of the buffer and drops the result: no branch in the stream)
         fx_fwd_interval<K, ACT, KS, RT>(Pb((i + 1) & 1), X, T((i + 1) & 1), slot, pv, Eg ? Eg + c0 + 32 : nullptr, egoff, w1,
                                         T(i & 1), reinterpret_cast<const float*>(Wb(i & 1)), it, WP, M, chok, Dg + c0, St(i & 1));
+        FXT(i, 2)
     }
     __syncthreads();
 }
@@ -917,7 +939,7 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
 //               dE(i) -> LDS, t1 / t2 partial sums;  Wr(i), cst2(i+1), taps(i+1) arrive meanwhile
 static size_t fx_bwde_lds(const TfnasCellDesc& d, const FxPlan& pl) {
     const int PAD = pl.KMAX / 2, HP = d.H + 2 * PAD, WP = (d.W + 2 * PAD) | 1;
-    const size_t de = (size_t)(((pl.NI * d.H * d.W + 15) / 16) * 16) * 128;
+    const size_t de = (size_t)(((pl.NI * d.H * d.W + 15) / 16) * 16 + 16) * 128;
     const size_t ddt = (size_t)(pl.NI * HP * WP + 8) * 128;
     return de + ddt + (size_t)(3 * d.ic * 64) + 512 + 2 * (size_t)pl.WB + 2048;
 }
@@ -928,18 +950,24 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
                                              const float* __restrict__ Dt, const float* __restrict__ gate,
                                              const float* __restrict__ dpooled, float* __restrict__ dxp,
                                              float* __restrict__ part, u8* lds, int ig, const FxSlice sl, int si) {
-    constexpr int PAD = K / 2, WBK = K * K * 128, WRB = 3 * CT * 16 * 64;
-    constexpr int NVR = (WRB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
-    constexpr int NR = 2 * RT;
+    // Seven worker waves + one copier wave, as in the forward (fx_fwd_body).  Per-wave cycle stamps (tools/fx_timeline.py) of the
+    // first version -- every wave loading, computing and copying -- showed ~2 200 of the 14 500 cycles of a chunk spent at the top of
+    // phase A waiting for the dZ / D loads issued just before the barrier, and ~1 500 in the stencil epilogue waiting for the blob
+    // copies issued just before the taps (the vector-memory counter is in-order: a wait for ehat drags every younger load along).
+    // Now: the copier moves Wr / taps / cst2 and writes the statistics rows; a worker issues dZ / D of chunk i + 1 at the TOP of
+    // phase B(i) and ehat of chunk i at the top of phase A(i): every load has a whole phase to land before anything waits for it.
+    constexpr int PAD = K / 2, WBK = K * K * 128, WRB = 3 * CT * 16 * 64, NW = FX_WORKERS, WT = 64 * NW;
+    constexpr int NCR = (WRB + 1023) / 1024, NCW = (WBK + 1023) / 1024;
+    constexpr int NR = 2 * RT;                       // rounds of the dd loader: 112 RT pixels x 8 quads / 448 worker threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, cq = tid & 7;
     const int H = d.H, W = d.W, HW = H * W, ic = d.ic, M = d.M;
     const int HP = H + 2 * PAD, WP = (W + 2 * PAD) | 1;
-    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW, ntiles = (NPX + 15) >> 4;
+    const int img0 = ig * pl.NI, nimg = min(pl.NI, d.N - img0), NPX = nimg * HW;
     const int g = sl.g, mcp = d.g[g].mcp, goff = d.g[g].off, nch = sl.nch;
     const bool has_se = d.g[g].se > 0;
     const float inv_hw = 1.f / (float)HW;
     const int PADM = pl.KMAX / 2;
-    const size_t de_b = (size_t)(((pl.NI * HW + 15) / 16) * 16) * 128;
+    const size_t de_b = (size_t)(((pl.NI * HW + 15) / 16) * 16 + 16) * 128;          // (+ a spare tile: pixel rows past the end)
     const size_t dd_b = (size_t)(pl.NI * (H + 2 * PADM) * ((W + 2 * PADM) | 1) + 8) * 128;
     float* DE = reinterpret_cast<float*>(lds);
     float* DD = reinterpret_cast<float*>(lds + de_b);
@@ -949,11 +977,70 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
     auto Wb = [&](int k) { return Wr + WRB + 512 + (k & 1) * wb_u; };
     float* St = reinterpret_cast<float*>(Wr + WRB + 512 + 2 * pl.WB);
 
+    for (size_t i = (size_t)tid * 16; i < dd_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + de_b + i) = u32x4{0, 0, 0, 0};
+    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
+    {
+        FxCopy<1> cw, cc;
+        cw.load(bl0 + pl.PB, WBK);
+        cc.load(bl0 + pl.PB + pl.WB, 512);
+        cw.store(Wb(0), WBK);
+        cc.store(reinterpret_cast<u8*>(C2), 512);
+    }
+    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
+
+    if (wave == NW) {
+        // ------------------------------------------------------------------------------------------------ copier wave
+        __syncthreads();
+        for (int i = 0; i <= nch; ++i) {
+            // phase A(i): the statistics of chunk i - 1; request Wr(i), taps(i + 1), cst2(i + 1)
+            if (i > 0) {
+                const int ch = lane & 31, which = lane >> 5, c0p = sl.c0 + 32 * (i - 1);
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += St[w * 64 + which * 32 + ch];
+                if (c0p + ch < mcp) prow[2 * (size_t)(c0p + ch) + which] = t;
+            }
+            if (i == nch) break;
+            const bool nx = i + 1 < nch;
+            const u8* bi = bl0 + (size_t)i * pl.BLOB, *bn = bl0 + (size_t)(nx ? i + 1 : i) * pl.BLOB;
+            u32x4 vr[NCR], vw[NCW], vc;
+#pragma unroll
+            for (int u = 0; u < NCR; ++u) {
+                const int o = (lane + 64 * u) * 16;
+                vr[u] = *reinterpret_cast<const u32x4*>(bi + pl.PB + pl.WB + 512 + (o < WRB ? o : WRB - 16));
+            }
+#pragma unroll
+            for (int u = 0; u < NCW; ++u) {
+                const int o = (lane + 64 * u) * 16;
+                vw[u] = *reinterpret_cast<const u32x4*>(bn + pl.PB + (o < WBK ? o : WBK - 16));
+            }
+            vc = *reinterpret_cast<const u32x4*>(bn + pl.PB + pl.WB + (lane < 32 ? lane * 16 : 0));
+            __syncthreads();
+            // phase B(i): nobody reads Wr, cst2 or the other tap buffer now
+#pragma unroll
+            for (int u = 0; u < NCR; ++u) {
+                const int o = (lane + 64 * u) * 16;
+                if (o < WRB) *reinterpret_cast<u32x4*>(Wr + o) = vr[u];
+            }
+            if (nx) {
+                u8* dw = Wb((i + 1) & 1);
+#pragma unroll
+                for (int u = 0; u < NCW; ++u) {
+                    const int o = (lane + 64 * u) * 16;
+                    if (o < WBK) *reinterpret_cast<u32x4*>(dw + o) = vw[u];
+                }
+                if (lane < 32) *reinterpret_cast<u32x4*>(reinterpret_cast<u8*>(C2) + lane * 16) = vc;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------------- worker waves
     int prow_[RT];
     bool pv[RT];
 #pragma unroll
     for (int pt = 0; pt < RT; ++pt) {
-        prow_[pt] = 16 * (wave + 8 * pt) + n;
+        prow_[pt] = 16 * (wave + NW * pt) + n;
         pv[pt] = prow_[pt] < NPX;
     }
     FxItem it;
@@ -964,8 +1051,8 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
         const int img = j / per_img, r = j - img * per_img, sc = r / H, oh = r - sc * H, ow0 = 4 * sc;
         const bool live = j < nimg * per_img;
         it.npx = live ? (W - ow0 < 4 ? W - ow0 : 4) : 0;
-        it.toff = ((img * HP + oh) * WP + ow0) * 32 + 4 * (lane & 7);
-        it.eoff = ((img * H + oh) * W + ow0) * 32 + 4 * (lane & 7);
+        it.toff = live ? ((img * HP + oh) * WP + ow0) * 32 + 4 * (lane & 7) : 4 * (lane & 7);
+        it.eoff = live ? ((img * H + oh) * W + ow0) * 32 + 4 * (lane & 7) : 4 * (lane & 7);
         eaddr = live ? ((size_t)img0 * HW + (size_t)(img * H + oh) * W + ow0) * M + goff + 4 * (lane & 7) : (size_t)goff;
     }
     int lslot[NR];
@@ -973,52 +1060,41 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
     int limg[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int pix = (tid + r * FX_THREADS) >> 3;
+        const int pix = (tid + r * WT) >> 3;
         const int pc = pix < NPX ? pix : NPX - 1;
         const int img = pc / HW, rr = pc - img * HW, h = rr / W, w = rr - h * W;
         lslot[r] = pix < NPX ? ((img * HP + h + PAD) * WP + w + PAD) * 32 + 4 * cq : -1;
         lpix[r] = (unsigned)pc;
         limg[r] = img;
     }
-    for (size_t i = (size_t)tid * 16; i < dd_b; i += FX_THREADS * 16) *reinterpret_cast<u32x4*>(lds + de_b + i) = u32x4{0, 0, 0, 0};
-    const u8* bl0 = blob + (size_t)sl.chunk0 * pl.BLOB;
-    {
-        FxCopy<1> cw, cc;
-        cw.load(bl0 + pl.PB, WBK);
-        cc.load(bl0 + pl.PB + pl.WB, 512);
-        cw.store(Wb(0), WBK);
-        cc.store(reinterpret_cast<u8*>(C2), 512);
-    }
     f32x4 dx[CT][RT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int pt = 0; pt < RT; ++pt) dx[ct][pt] = zero4();
-    __syncthreads();
-
     const size_t pixbase = (size_t)img0 * HW;
-    float* prow = part + (size_t)ig * 2 * M + 2 * (size_t)goff;
-    // (all global loads are issued one phase before their use: dZ / D of chunk i + 1 at the top of phase B(i), ehat of chunk i at
-    //  the top of phase A(i) -- with loads issued and consumed inside one phase the kernel without ANY arithmetic still took 70 % of
-    //  its time, tools/r5_fxabl.sh)
     f32x4 dz[NR], dv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const size_t a = (pixbase + lpix[r]) * M + goff + sl.c0 + 4 * cq;
-        dz[r] = ld4_nt(dZ + a);
-        dv[r] = ld4_nt(Dt + a);
+        dz[r] = (FX_ABL & 512) ? splat4(0.25f) : ld4_nt(dZ + a);
+        dv[r] = (FX_ABL & 512) ? splat4(0.75f) : ld4_nt(Dt + a);
     }
+    __syncthreads();
     for (int i = 0; i <= nch; ++i) {
         const int c0 = sl.c0 + 32 * i;
         const bool chok = c0 + 4 * cq < mcp;
-        // ---- phase A: dd(i) -> LDS  ||  dx += dE(i - 1) Wr(i - 1)   (the two halves of the workgroup in opposite order)
+        // ---- phase A: dx += dE(i - 1) Wr(i - 1)  (MFMA);  dd(i) = BN2-backward(dZ, D) -> LDS image tile
+        FXT(i, 0)
         f32x4 ev[4];
         {
             const int ce = i < nch ? c0 : c0 - 32;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) ev[jj] = ld4_nt(Eh + eaddr + ce + (size_t)(jj < it.npx ? jj : 0) * M);
+            for (int jj = 0; jj < 4; ++jj)
+                ev[jj] = (FX_ABL & 256) ? splat4(0.5f) : ld4_nt(Eh + eaddr + ce + (size_t)(jj < it.npx ? jj : 0) * M);
         }
-        auto gstep = [&]() __attribute__((always_inline)) {
+        FXT(i, 1)
+        if (i > 0) {
             bf16x8 bh[RT], bm[RT], bl[RT];
 #pragma unroll
             for (int pt = 0; pt < RT; ++pt) {
@@ -1045,39 +1121,41 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
                 FX_GTERM(al, bh) FX_GTERM(am, bm) FX_GTERM(ah, bl) FX_GTERM(am, bh) FX_GTERM(ah, bm) FX_GTERM(ah, bh)
 #undef FX_GTERM
             }
-        };
-        auto commit = [&]() __attribute__((always_inline)) {
+        }
+        FXT(i, 2)
+        if (i == nch) break;
+        // (the MFMAs and the BN2-backward transform below were also tried as ONE interleaved stream, a column-tile pair + a loader
+        //  round per scheduling region: 5 750 cycles against 2 200 + 3 170 -- no gain, tools/fx_timeline.py)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (lslot[r] >= 0) {
+                f32x4 g4 = zero4(), dp4 = zero4();
+                if (has_se) {
+                    const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
+                    g4 = ld4(gate + o);
+                    dp4 = ld4(dpooled + o) * splat4(inv_hw);
+                }
+                f32x4 v = (FX_ABL & 128) ? dz[r] + dv[r] : fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
+                if (!chok) v = zero4();
+                st4(DD + lslot[r], v);
+            }
+        }
+        FXT(i, 3)
+        __syncthreads();
+        FXT(i, 4)
+        // ---- phase B: dZ / D of chunk i + 1 requested; stencil of chunk i (flipped taps), * act'(ehat), dE -> LDS, t1 / t2
+        // (requested at the END of the phase instead -- behind the wait for ehat -- the next phase A opens with a ~2 000-cycle wait:
+        //  the compiler puts a vmcnt(0) in front of the ehat requests; measured, tools/fx_timeline.py)
+        {
+            const int cn = i + 1 < nch ? c0 + 32 : c0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (lslot[r] >= 0) {
-                    f32x4 g4 = zero4(), dp4 = zero4();
-                    if (has_se) {
-                        const size_t o = (size_t)(img0 + limg[r]) * M + goff + c0 + 4 * cq;
-                        g4 = ld4(gate + o);
-                        dp4 = ld4(dpooled + o) * splat4(inv_hw);
-                    }
-                    f32x4 v = (FX_ABL & 128) ? dz[r] + dv[r] : fx_bn2_dd<ACT>(C2 + 4 * cq, dz[r], dv[r], has_se, g4, dp4);
-                    if (!chok) v = zero4();
-                    st4(DD + lslot[r], v);
-                }
+                const size_t a = (pixbase + lpix[r]) * M + goff + cn + 4 * cq;
+                dz[r] = (FX_ABL & 512) ? splat4(0.25f) : ld4_nt(dZ + a);
+                dv[r] = (FX_ABL & 512) ? splat4(0.75f) : ld4_nt(Dt + a);
             }
-        };
-        // (loads are consumed in the order they were issued -- the vector-memory counter is in-order, a wait for an older load
-        //  must not find younger ones it would have to wait for as well: dZ / D (i) [end of phase B(i-1)] -> ehat (i) [here] ->
-        //  blob pieces [top of phase B(i)] -> dZ / D (i+1) [end of phase B(i)])
-        if (i > 0) fx_stat_emit(St, prow, c0 - 32, mcp);
-        if (i > 0) gstep();
-        if (i == nch) break;
-        commit();
-        __syncthreads();
-        // ---- phase B: stencil of chunk i; the next blob pieces arrive meanwhile, dZ / D of chunk i + 1 are requested at its end
-        const bool nx = i + 1 < nch;
-        FxCopy<NVR> cr;
-        FxCopy<1> cw, cc;
-        const u8* bi = bl0 + (size_t)i * pl.BLOB, *bn = bl0 + (size_t)(nx ? i + 1 : i) * pl.BLOB;
-        cr.load(bi + pl.PB + pl.WB + 512, WRB);
-        cw.load(bn + pl.PB, WBK);
-        cc.load(bn + pl.PB + pl.WB, 512);
+        }
+        FXT(i, 5)
         {
             const float* taps = reinterpret_cast<const float*>(Wb(i & 1));
             f32x4 t1 = zero4(), t2 = zero4();
@@ -1097,6 +1175,7 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
                     for (int jj = 0; jj < 4; ++jj) acc[jj] += win[jj + kx] * wv;
                 }
             }
+            FXT(i, 6)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const bool ok = chok && jj < it.npx;
@@ -1110,21 +1189,9 @@ __device__ __forceinline__ void fx_bwde_body(const TfnasCellDesc& d, const FxPla
             }
             fx_stat_park(t1, t2, St);
         }
-        cr.store(Wr, WRB);
-        if (nx) {
-            cw.store(Wb((i + 1) & 1), WBK);
-            cc.store(reinterpret_cast<u8*>(C2), 512);
-        }
-        {
-            const int cn = nx ? c0 + 32 : c0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const size_t a = (pixbase + lpix[r]) * M + goff + cn + 4 * cq;
-                dz[r] = ld4_nt(dZ + a);
-                dv[r] = ld4_nt(Dt + a);
-            }
-        }
+        FXT(i, 7)
         __syncthreads();
+        FXT(i, 10)
     }
     float* __restrict__ dst = dxp + (size_t)si * d.N * HW * ic;
 #pragma unroll
@@ -1321,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_fx_stats1(TfnasCellDesc d, const double
 // scratch (`part`): partial rows from the bottom, the double results xsum[ic] | C[ic * ic] in the top
 int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, float* part, hipStream_t s) {
     const int P = d.N * d.H * d.W, ic = d.ic, ne = ic * ic;
-    int nb = 256;
+    int nb = 256;        // row blocks = partial Gram matrices, x 4 column-tile workgroups each (64 blocks: slower, the loop is a latency chain)
     while (nb > 1 && (size_t)nb * ne + 2 * (size_t)(ne + ic + 4) + 64 > TFNAS_PART_FLOATS) nb >>= 1;
     int rps = cdiv(P, nb);
     rps = (rps + 3) & ~3;
@@ -1484,7 +1551,7 @@ int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const
     {                                                                            \
         if (d.act == TFNAS_ACT_RELU) FX_BWD(0, CT_, RT_) else FX_BWD(1, CT_, RT_) \
     }
-        const int key = (d.ic / 16) * 10 + pl.RT;
+        const int key = (d.ic / 16) * 10 + (Eh ? pl.RTF : pl.RT);
         switch (key) {
             case 41: FX_BWD_A(4, 1) break;
             case 42: FX_BWD_A(4, 2) break;
