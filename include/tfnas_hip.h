@@ -180,6 +180,11 @@ int tfnas_efree_supported(const TfnasCellDesc *d);
  * slice of mid channels; neither E nor its gradient is ever written (the dEh buffer of tfnas_mixedop_bwd is used as scratch for
  * partial sums of dx).  Implies tfnas_efree_supported. */
 int tfnas_fx_supported(const TfnasCellDesc *d);
+/* 1 when the FORWARD of an E-free launch of the (planned) cell takes the stride-2 tiled fused kernel (csrc/fx_s2.inc): stride 2,
+ * ic <= 24 (a multiple of 8), every candidate wider than 32 mid channels, frozen weights -- the supernet's down-sampling cells at
+ * 112 -> 56 and 56 -> 28 pixels.  Same arithmetic as the fused per-image route, one 4 x 14 output tile at a time; the backward of
+ * these cells stays on the E-free tile kernels. */
+int tfnas_fx2_supported(const TfnasCellDesc *d);
 
 /* MixedOP forward.
  *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):

@@ -245,6 +245,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     } while (0)
 
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
+extern "C" int tfnas_fx2_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp) && fx2_supported(*dp)) ? 1 : 0; }
 extern "C" int tfnas_fx_supported(const TfnasCellDesc* dp) {
     return (dp && dp->mode == TFNAS_MODE_CELL && !dp->need_wgrad && !efree_ic_small(dp->ic) && fx_supported(*dp)) ? 1 : 0;
 }
@@ -289,6 +290,7 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
     if (sync) TRY(stats_sync(d, stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
     if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
     if (fx) TRY(launch_fx_fwd(d, b.x, stats1, b.E, b.D, stats2, b.part, s));  // expand + BN1 + act + depthwise in one kernel
+    else if (!b.E && !bn && fx2_supported(d)) TRY(launch_fx2_fwd(d, b.x, stats1, b.D, stats2, b.part, s));   // stride 2, tiled
     else TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));     // BN1+act fused load, depthwise, BN2 statistics
     if (sync) TRY(stats_sync(d, stats2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));

@@ -74,6 +74,10 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
 // recomputing it; E == nullptr: nothing is stored, the backward rebuilds ehat from x
 int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* E, float* D, double* stats2,
                   float* part, hipStream_t s);
+// stride-2 tiled variant of the fused forward (fx_s2.inc): E-free launches (E == nullptr) of cells with stride 2, ic <= 24
+bool fx2_supported(const TfnasCellDesc& d);
+int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* D, double* stats2, float* part,
+                   hipStream_t s);
 // backward: the partial sums of dE (rstd . W1) into scratch[0 .. nsl * P * ic) (nsl returned), the BN1-backward sums into
 // red1 and the cb1 table; the caller finishes with launch_expand_gram + launch_expand_dgrad_x(scratch, nsl)
 int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const double* stats1, const double* stats2,

@@ -102,6 +102,7 @@ _PROTOS = {
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_fx_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
+    'tfnas_fx2_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_arch_project': (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),

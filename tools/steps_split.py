@@ -33,6 +33,7 @@ def med(f):
     return ts[len(ts) // 2], ts[0]
 
 
-w = med(lambda: search.w_step(state, x, y, opt_w, 5.0, noise.exp(dev), noise.rand_pos()))
-a = med(lambda: search.a_step(state, x, y, opt_a, 15.0, 0.1, 5.0, noise.exp(dev)))
+only = os.environ.get('STEPS_ONLY', '')          # 'w' / 'a': one loop only (a rocprofv3 --stats run of one step kind)
+w = med(lambda: search.w_step(state, x, y, opt_w, 5.0, noise.exp(dev), noise.rand_pos())) if only != 'a' else (0., 0.)
+a = med(lambda: search.a_step(state, x, y, opt_a, 15.0, 0.1, 5.0, noise.exp(dev))) if only != 'w' else (0., 0.)
 print('w_step median %.2f ms (min %.2f) | a_step median %.2f ms (min %.2f)' % (w[0], w[1], a[0], a[1]), flush=True)
