@@ -110,6 +110,7 @@ typedef struct TfnasCellDesc {
 } TfnasCellDesc;
 #define TFNAS_GEMM_EXPLICIT 0x1000
 #define TFNAS_CELL_LAZY_JOIN 1
+#define TFNAS_CELL_FX2 2       /* E-free forward of a stride-2 cell: take the tiled fused kernel when tfnas_fx2_supported (csrc/fx_s2.inc) */
 
 /* Element counts / offsets of every caller-allocated buffer of one cell. */
 typedef struct TfnasCellWs {
@@ -183,7 +184,8 @@ int tfnas_fx_supported(const TfnasCellDesc *d);
 /* 1 when the FORWARD of an E-free launch of the (planned) cell takes the stride-2 tiled fused kernel (csrc/fx_s2.inc): stride 2,
  * ic <= 24 (a multiple of 8), every candidate wider than 32 mid channels, frozen weights -- the supernet's down-sampling cells at
  * 112 -> 56 and 56 -> 28 pixels.  Same arithmetic as the fused per-image route, one 4 x 14 output tile at a time; the backward of
- * these cells stays on the E-free tile kernels. */
+ * these cells stays on the E-free tile kernels.  A VARIANT, not the default: measured slower than the E-free tile kernel on
+ * MI355X; taken only when the descriptor carries TFNAS_CELL_FX2 (or the process runs with TFNAS_FX2=1). */
 int tfnas_fx2_supported(const TfnasCellDesc *d);
 
 /* MixedOP forward.

@@ -41,6 +41,19 @@ FX2_CASES = [
 ]
 
 
+def _want_fx2(m, case):
+    """FX2_CASES run with the model-level switch of the variant (HipModes.fx2 -> TFNAS_CELL_FX2 on every descriptor)."""
+    if case not in FX2_CASES:
+        return
+    import ctypes as C
+    from tfnas_amd import _lib, functions as F
+    F.adopt_modes(m, F.HipModes(fx2=True))
+    plan = m._plan(tuple(range(8)))
+    d, _ = plan.desc(case[0], case[5], case[6])
+    plan.bind(d, plan.params())
+    assert d.flags & _lib.CELL_FX2 and _lib.lib().tfnas_fx2_supported(C.byref(d)) == 1
+
+
 def _run(m, x, r, e, idxs, efree):
     from tfnas_amd import functions as F
     from tfnas_amd.functions import MixedOpFn
@@ -68,6 +81,7 @@ def test_efree_matches_e_path(case, idxs):
     N, ic, oc, stride, act, H, W = case
     mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
     o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=ic + stride)
+    _want_fx2(m, case)
     g = torch.Generator().manual_seed(7 * ic + H)
     x = torch.randn(N, ic, H, W, generator=g) * 1.5 + 0.7          # non-zero channel means: the Gram path must centre
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -101,6 +115,7 @@ def test_efree_matches_oracle_stage_by_stage(case):
     N, ic, oc, stride, act, H, W = case
     mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
     o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=3)
+    _want_fx2(m, case)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, ic, H, W, generator=g) + 0.3
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1

@@ -111,6 +111,30 @@ def test_host_gumbel_positions_match_the_oracle_cell_by_cell():
         assert search.host_gumbel_positions(la, e, 5.0) == want
 
 
+def test_alpha_host_copy_follows_the_invalidation_rule(net):
+    """SearchState.alpha_host is keyed on (data_ptr, _version): re-assignment and in-place ops on the parameter re-stage it, an
+    edit through `.data` does not (the rule documented at invalidate_alpha_host) until the hook is called."""
+    from tfnas_amd import search
+    st = search.SearchState(net, weak_model=True)
+    cell = net.cells()[3]
+    keep = cell.log_alphas.data.clone()
+    try:
+        a0 = st.alpha_host().clone()
+        cell.log_alphas.data = torch.log_softmax(torch.randn(8), -1)          # the reference's renormalisation: new storage
+        a1 = st.alpha_host().clone()
+        assert not torch.equal(a0[3], a1[3]) and torch.equal(a1[3], cell.log_alphas.detach())
+        with torch.no_grad():
+            cell.log_alphas.mul_(0.5)                                         # in-place on the parameter: version bump
+        assert torch.equal(st.alpha_host()[3], cell.log_alphas.detach())
+        cell.log_alphas.data.add_(1.0)                                        # through .data: invisible to the key
+        assert not torch.equal(st.alpha_host()[3], cell.log_alphas.detach())
+        st.invalidate_alpha_host()
+        assert torch.equal(st.alpha_host()[3], cell.log_alphas.detach())
+    finally:
+        cell.log_alphas.data = keep
+        st.release()
+
+
 def test_parsing_known_answers_and_lut_builder_key_set(tmp_path):
     """Derived-network config / MAC / parameter counts (values the reference's model_eval + flops_benchmark give, checked in
     tests/test_oracle_vs_reference.py) and the LUT builder's key set == the keys of the shipped reference tables."""

@@ -1487,18 +1487,23 @@ static bool fx_enabled() {
     return on;
 }
 
-// stride-2 tiled forward (fx_s2.inc): E-free launches of the early down-sampling cells
+// stride-2 tiled forward (fx_s2.inc): E-free launches of the early down-sampling cells that carry TFNAS_CELL_FX2, or all of them
+// with TFNAS_FX2 = 1 (default 0): measured
+// SLOWER than the E-free tile kernel (cell 0: 1.75 vs 1.36 ms, cell 2: 0.74 vs 0.68 ms; DESIGN.md section 4d has the ablation),
+// kept as a tested variant
 static bool fx2_enabled() {
     static const bool on = [] {
         const char* e = getenv("TFNAS_FX2");
-        return e ? e[0] != '0' : true;
+        return e ? e[0] != '0' : false;
     }();
     return on;
 }
 
+bool fx2_wanted(const TfnasCellDesc& d) { return fx2_enabled() || (d.flags & TFNAS_CELL_FX2); }
+
 bool fx2_supported(const TfnasCellDesc& d) {
     FxPlan pl;
-    if (!fx_enabled() || !fx2_enabled() || !fx2_plan(d, pl)) return false;
+    if (!fx_enabled() || !fx2_plan(d, pl)) return false;
     if (d.ic > 24) return false;                            // (staging: 8 x-pieces per lane of waves 4..7 per tile)
     if (fx2_lds(d, pl) > 160 * 1024) return false;
     const size_t rows = (((size_t)d.N * 2 * d.M) + 63) & ~(size_t)63, blobs = ((size_t)pl.nchunks * pl.BLOB + 3) / 4;

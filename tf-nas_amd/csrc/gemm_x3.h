@@ -34,6 +34,11 @@ __device__ __forceinline__ float x3_float(unsigned v) { return __builtin_bit_cas
 // upper halves (= truncated bf16) of two floats in one dword: low half <- a, high half <- b
 __device__ __forceinline__ unsigned x3_pack(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// Non-finite and tiny operands: an Inf operand splits into h = Inf, r1 = Inf - Inf = NaN, so the products carry NaN
+// where the fp32 MFMA loop would carry Inf -- non-finite either way, never a finite wrong number (bench.py and the search
+// loop's finiteness check treat both the same; a guard would cost two VALU operations per operand element in the hottest loop).
+// bf16 has fp32's exponent range, so the residues m / l only vanish where fp32 itself goes denormal (|v| < 2^-126 * 2^16 for l),
+// and the matrix core flushes denormal inputs in both forms.
 struct X3Planes { u32x2 h, m, l; };   // four values -> three planes of four bf16
 template <int TERMS>
 __device__ __forceinline__ X3Planes x3_split4(f32x4 v) {

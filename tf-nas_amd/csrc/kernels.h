@@ -76,6 +76,7 @@ int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, 
                   float* part, hipStream_t s);
 // stride-2 tiled variant of the fused forward (fx_s2.inc): E-free launches (E == nullptr) of cells with stride 2, ic <= 24
 bool fx2_supported(const TfnasCellDesc& d);
+bool fx2_wanted(const TfnasCellDesc& d);      // TFNAS_CELL_FX2 on the descriptor, or TFNAS_FX2=1
 int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* D, double* stats2, float* part,
                    hipStream_t s);
 // backward: the partial sums of dE (rstd . W1) into scratch[0 .. nsl * P * ic) (nsl returned), the BN1-backward sums into

@@ -22,7 +22,7 @@ _W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e
 _G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
 
 
-GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN = 0x1000, 0x100, 1
+GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN, CELL_FX2 = 0x1000, 0x100, 1, 2
 GEMM_MODES = {'f32': 0, 'bf16': 1, 'x2': 3, 'x3': 6}
 
 

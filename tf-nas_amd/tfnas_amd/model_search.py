@@ -511,10 +511,20 @@ class Network(nn.Module):
             out = runner.sampled(feat, idxs, name='A' if mode == 'gumbel' else 'B', expose=st)
             return self.classifier(self._head(out)), 0.0
         side.wait_event(first[1])
+        # device tensors the caller made AFTER the first forward was entered (rand_pos / exp_noise of this call) are produced on
+        # the caller's stream: the side stream must see them finished -- one more event, recorded now
+        late = [t for t in (exp_noise, rand_pos) if torch.is_tensor(t) and t.is_cuda]
+        if late:
+            ev2 = torch.cuda.Event()
+            ev2.record(cur)
+            side.wait_event(ev2)
+            for t in late:
+                t.record_stream(side)
         x.record_stream(side)
         if not st.__dict__.get('_warned_off'):
             # the stems' AccumulateGrad nodes now receive one of their two gradients from the side stream -- intended (the engine
-            # synchronises them); torch >= 2.9 warns about exactly this on every backward
+            # synchronises them); torch >= 2.9 warns about exactly this on every backward.  NB the switch is process-wide: it
+            # also silences the diagnostic for other models in the process (set SECOND_PATH_ON_SIDE_STREAM = False to keep it)
             off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
             if off is not None:
                 off(False)

@@ -460,8 +460,16 @@ class SearchState:
         self._pin_ev.record(torch.cuda.current_stream(la.device))
         self._alpha_host = (self._alpha_key(), self._pin, self._pin_ev)
 
+    def invalidate_alpha_host(self):
+        """Forget the host copy of the log_alphas.  It is keyed on (data_ptr, _version) of every parameter, which covers
+        re-assignment (`p.data = ...`, the reference's renormalisation after the optimizer step) and in-place ops on the
+        parameter itself -- NOT in-place edits through `.data` / `.detach()` views (`p.data.clamp_()`, `p.data.copy_()`) or raw
+        kernels writing the storage, which change neither: call this after such an edit, or the next host-sampled forward draws
+        its candidates from the stale values."""
+        self._alpha_host = None
+
     def alpha_host(self):
-        """Host copy of the log_alphas, or None when they were modified since it was staged."""
+        """Host copy of the log_alphas (re-staged when they were modified since: see invalidate_alpha_host for the rule)."""
         if self._alpha_host is None or self._alpha_host[0] != self._alpha_key():
             self.stage_alpha_host()
         _, buf, ev = self._alpha_host
