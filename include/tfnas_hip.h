@@ -110,6 +110,8 @@ typedef struct TfnasCellDesc {
 } TfnasCellDesc;
 #define TFNAS_GEMM_EXPLICIT 0x1000
 #define TFNAS_CELL_LAZY_JOIN 1
+#define TFNAS_CELL_FXP 4       /* backward of a cell with <= 14 x 14 output pixels: dZ and the BN2-backward tables from the fused per-image
+                                  project dgrad when tfnas_fxp_supported (csrc/fx_pd.inc) */
 #define TFNAS_CELL_FX2 2       /* E-free forward of a stride-2 cell: take the tiled fused kernel when tfnas_fx2_supported (csrc/fx_s2.inc) */
 
 /* Element counts / offsets of every caller-allocated buffer of one cell. */
@@ -187,6 +189,10 @@ int tfnas_fx_supported(const TfnasCellDesc *d);
  * these cells stays on the E-free tile kernels.  A VARIANT, not the default: measured slower than the E-free tile kernel on
  * MI355X; taken only when the descriptor carries TFNAS_CELL_FX2 (or the process runs with TFNAS_FX2=1). */
 int tfnas_fx2_supported(const TfnasCellDesc *d);
+/* 1 when the project data gradient of the (planned) cell can run as the fused per-image kernel (csrc/fx_pd.inc): at most 14 x 14
+ * output pixels, 16 <= oc <= 256 (a multiple of 4).  dZ = dP W_proj and the per-image BN2-backward tables in one pass, the
+ * BN3-backward operand resident in registers.  A VARIANT (TFNAS_CELL_FXP / TFNAS_FXP=1): measured equal to the default kernels. */
+int tfnas_fxp_supported(const TfnasCellDesc *d);
 
 /* MixedOP forward.
  *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):

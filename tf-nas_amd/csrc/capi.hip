@@ -168,7 +168,7 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         const int gm = d->gemm_mode & ~(TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_EVERYWHERE);
         if (!(d->gemm_mode & TFNAS_GEMM_EXPLICIT) || (gm != 0 && gm != 1 && gm != 3 && gm != 6)) return TFNAS_EINVAL;
     }
-    if (d->flags & ~(TFNAS_CELL_LAZY_JOIN | TFNAS_CELL_FX2)) return TFNAS_EINVAL;
+    if (d->flags & ~(TFNAS_CELL_LAZY_JOIN | TFNAS_CELL_FX2 | TFNAS_CELL_FXP)) return TFNAS_EINVAL;
     if (d->sync_fn && d->sync_world < 1) return TFNAS_ERANGE;
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
@@ -246,6 +246,7 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
 
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
 extern "C" int tfnas_fx2_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp) && fx2_supported(*dp)) ? 1 : 0; }
+extern "C" int tfnas_fxp_supported(const TfnasCellDesc* dp) { return (dp && fxp_supported(*dp, (size_t)1 << 40)) ? 1 : 0; }
 extern "C" int tfnas_fx_supported(const TfnasCellDesc* dp) {
     return (dp && dp->mode == TFNAS_MODE_CELL && !dp->need_wgrad && !efree_ic_small(dp->ic) && fx_supported(*dp)) ? 1 : 0;
 }
@@ -388,7 +389,10 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     //  write-bound all-candidate launches of the 112 x 112 / 56 x 56 cells -- cell 1: 0.99 -> 1.04 ms -- and less everywhere else:
     //  cell 10 sampled 0.126 -> 0.103 ms, cell 15 all candidates 0.286 -> 0.252 ms)
     const bool fold = fused2 && g_project_fold && project_fold_ok(d, (size_t)ws.dEh) && (d.G == 1 || d.Ho * d.Wo <= 784);
-    if (fold) {
+    if (fused2 && b.D && fxp_wanted(d) && fxp_supported(d, (size_t)ws.dEh)) {
+        // late cells (<= 14 x 14 output pixels): dZ and the tables in one fused per-image kernel (fx_pd.inc)
+        TRY(launch_fx_pdgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.D, stats2, b.dZ, part, dgate, b.dEh, s));
+    } else if (fold) {
         TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s, b.D, stats2, b.dEh));
         TRY(launch_bn2_gather(d, b.dEh, dgate, part, s));
     } else {

@@ -1540,6 +1540,73 @@ int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1,
     return launch_reduce_rows(part, d.N, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
+#include "fx_pd.inc"
+
+// The fused per-image project dgrad (fx_pd.inc) runs for descriptors that carry TFNAS_CELL_FXP, or everywhere it applies with
+// TFNAS_FXP = 1 (default 0): measured EQUAL to k_project_dgrad + k_bn2_gather (cell 10: 0.388 vs 0.391 ms, cell 6: 0.264 vs 0.253,
+// cell 15: 0.267 vs 0.222) -- both are bound by VALU issue, not by the matrix pipe -- so it stays a tested variant
+static bool fxp_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("TFNAS_FXP");
+        return e ? e[0] != '0' : false;
+    }();
+    return on;
+}
+bool fxp_wanted(const TfnasCellDesc& d) { return fxp_enabled() || (d.flags & TFNAS_CELL_FXP); }
+
+bool fxp_supported(const TfnasCellDesc& d, size_t scratch_floats) {
+    FxPlan pl;
+    if (!fxp_plan(d, pl)) return false;
+    if (fxp_lds(d, pl) > 160 * 1024) return false;
+    // (+ a spare line per wave for the unconditional stores)
+    return ((size_t)pl.nchunks * pl.BLOB + 3) / 4 + (size_t)pl.nig * pl.nslices * 8 * 32 + 64 <= scratch_floats;
+}
+
+// scratch: the blobs (the cell's dEh buffer: nothing reads or writes it before the SE backward)
+int launch_fx_pdgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3, const double* red3,
+                     const float* wmix, const float* D, const double* stats2, float* dZ, float* pp, float* dgate, float* scratch,
+                     hipStream_t s) {
+    FxPlan pl;
+    if (!fxp_plan(d, pl)) return TFNAS_EINVAL;
+    u8* blob = reinterpret_cast<u8*>(scratch);
+    {
+        ProfScope _prof(TK_SMALL, s);
+        hipLaunchKernelGGL(k_fxp_pack, dim3(pl.nchunks, 4), dim3(256), 0, s, d, pl, stats2, blob);
+    }
+    const size_t shm = fxp_lds(d, pl);
+    const dim3 grid(pl.nig * pl.nslices);
+    ProfScope _prof(TK_PROJECT_DGRAD, s);
+#define FXP_L(A_, KS_, RT_)                                                                                              \
+    {                                                                                                                    \
+        static bool attr = fx_attr_done((const void*)k_fx_pdgrad<A_, KS_, RT_>, 160 * 1024);                             \
+        if (!attr) return TFNAS_EINVAL;                                                                                  \
+        hipLaunchKernelGGL((k_fx_pdgrad<A_, KS_, RT_>), grid, dim3(FX_THREADS), shm, s, d, pl, dout, Pr, stats3, red3,   \
+                           wmix, D, blob, dZ, pp, dgate);                                                                \
+    }
+#define FXP_A(KS_, RT_)                                                      \
+    {                                                                        \
+        if (d.act == TFNAS_ACT_RELU) FXP_L(0, KS_, RT_) else FXP_L(1, KS_, RT_) \
+    }
+    switch (pl.KS * 10 + pl.RT) {
+        case 11: FXP_A(1, 1) break;
+        case 12: FXP_A(1, 2) break;
+        case 21: FXP_A(2, 1) break;
+        case 22: FXP_A(2, 2) break;
+        case 31: FXP_A(3, 1) break;
+        case 32: FXP_A(3, 2) break;
+        case 41: FXP_A(4, 1) break;
+        case 42: FXP_A(4, 2) break;
+        case 51: FXP_A(5, 1) break;
+        case 61: FXP_A(6, 1) break;
+        case 71: FXP_A(7, 1) break;
+        case 81: FXP_A(8, 1) break;
+        default: return TFNAS_EINVAL;
+    }
+#undef FXP_A
+#undef FXP_L
+    return (int)hipGetLastError();
+}
+
 // scratch layout of the backward: dxp [nsl + 1][P][ic] floats | blobs (256-byte aligned) -- in `scratch` (the cell's dEh buffer,
 // which the fused route never uses for dE) when it is large enough, else the blobs go behind the statistics rows in `part`
 static bool fx_bwd_layout(const TfnasCellDesc& d, const FxPlan& pl, size_t scratch_floats, size_t& blob_off_scratch,

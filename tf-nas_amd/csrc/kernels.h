@@ -79,6 +79,13 @@ bool fx2_supported(const TfnasCellDesc& d);
 bool fx2_wanted(const TfnasCellDesc& d);      // TFNAS_CELL_FX2 on the descriptor, or TFNAS_FX2=1
 int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* D, double* stats2, float* part,
                    hipStream_t s);
+// fused per-image project dgrad (fx_pd.inc): dZ + the per-image BN2-backward tables pp / dgate (what k_bn2_pool writes) in one pass,
+// for cells with at most 14 x 14 output pixels and oc <= 256; scratch (blobs): scratch_floats floats
+bool fxp_supported(const TfnasCellDesc& d, size_t scratch_floats);
+bool fxp_wanted(const TfnasCellDesc& d);      // TFNAS_CELL_FXP on the descriptor, or TFNAS_FXP=1
+int launch_fx_pdgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3, const double* red3,
+                     const float* wmix, const float* D, const double* stats2, float* dZ, float* pp, float* dgate, float* scratch,
+                     hipStream_t s);
 // backward: the partial sums of dE (rstd . W1) into scratch[0 .. nsl * P * ic) (nsl returned), the BN1-backward sums into
 // red1 and the cb1 table; the caller finishes with launch_expand_gram + launch_expand_dgrad_x(scratch, nsl)
 int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const double* stats1, const double* stats2,
