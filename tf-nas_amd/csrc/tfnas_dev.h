@@ -22,7 +22,11 @@ static inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 // 1/(1+e^-x) through v_exp_f32 + v_rcp_f32 (1 ulp each).  An IEEE `/` costs ~10 more VALU instructions per element
 // (v_div_scale x2, fma chain, v_div_fmas, v_div_fixup), and the operand loaders that apply the activation are VALU-issue
 // bound: 682 VALU instructions per 32 MFMAs in k_project_fwd<4, swish> before this.
+#ifdef TFNAS_FAKE_SIGMOID      // timing-only build (tools/r5_sigmoid.sh): what the two transcendentals of every swish / swish' cost
+__device__ __forceinline__ float sigmoid_f(float x) { return fmaf(x, 0.25f, 0.5f); }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+#endif
 template <int ACT>
 __device__ __forceinline__ float act_f(float x) {
     if (ACT == TFNAS_ACT_RELU) return fmaxf(x, 0.f);
