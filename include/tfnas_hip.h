@@ -112,7 +112,6 @@ typedef struct TfnasCellDesc {
 #define TFNAS_CELL_LAZY_JOIN 1
 #define TFNAS_CELL_FXP 4       /* backward of a cell with <= 14 x 14 output pixels: dZ and the BN2-backward tables from the fused per-image
                                   project dgrad when tfnas_fxp_supported (csrc/fx_pd.inc) */
-#define TFNAS_CELL_FX2 2       /* E-free forward of a stride-2 cell: take the tiled fused kernel when tfnas_fx2_supported (csrc/fx_s2.inc) */
 
 /* Element counts / offsets of every caller-allocated buffer of one cell. */
 typedef struct TfnasCellWs {
@@ -183,12 +182,6 @@ int tfnas_efree_supported(const TfnasCellDesc *d);
  * slice of mid channels; neither E nor its gradient is ever written (the dEh buffer of tfnas_mixedop_bwd is used as scratch for
  * partial sums of dx).  Implies tfnas_efree_supported. */
 int tfnas_fx_supported(const TfnasCellDesc *d);
-/* 1 when the FORWARD of an E-free launch of the (planned) cell takes the stride-2 tiled fused kernel (csrc/fx_s2.inc): stride 2,
- * ic <= 24 (a multiple of 8), every candidate wider than 32 mid channels, frozen weights -- the supernet's down-sampling cells at
- * 112 -> 56 and 56 -> 28 pixels.  Same arithmetic as the fused per-image route, one 4 x 14 output tile at a time; the backward of
- * these cells stays on the E-free tile kernels.  A VARIANT, not the default: measured slower than the E-free tile kernel on
- * MI355X; taken only when the descriptor carries TFNAS_CELL_FX2 (or the process runs with TFNAS_FX2=1). */
-int tfnas_fx2_supported(const TfnasCellDesc *d);
 /* 1 when the project data gradient of the (planned) cell can run as the fused per-image kernel (csrc/fx_pd.inc): at most 14 x 14
  * output pixels, 16 <= oc <= 256 (a multiple of 4).  dZ = dP W_proj and the per-image BN2-backward tables in one pass, the
  * BN3-backward operand resident in registers.  A VARIANT (TFNAS_CELL_FXP / TFNAS_FXP=1): measured equal to the default kernels. */

@@ -70,8 +70,8 @@ def test_plan_and_workspace_geometry(lib):
 
 
 def test_fused_route_queries_on_the_supernet_geometries(lib):
-    """tfnas_fx_supported / tfnas_fx2_supported / tfnas_fxp_supported are host-side plan logic (no launch): which of the supernet's
-    18 cells (batch 128, all candidates, frozen weights) each fused route covers, the variant flags, and what switches them off."""
+    """tfnas_fx_supported / tfnas_fxp_supported are host-side plan logic (no launch): which of the supernet's 18 cells (batch 128,
+    all candidates, frozen weights) each fused route covers, the variant flag, and what switches them off."""
     from tfnas_amd import _lib
     cells = [(16, 24, 2, 112), (24, 24, 1, 56), (24, 40, 2, 56), (40, 40, 1, 28), (40, 40, 1, 28), (40, 80, 2, 28),
              (80, 80, 1, 14), (80, 80, 1, 14), (80, 80, 1, 14), (80, 112, 1, 14), (112, 112, 1, 14), (112, 112, 1, 14),
@@ -81,22 +81,22 @@ def test_fused_route_queries_on_the_supernet_geometries(lib):
         mids = (3 * ic, 6 * ic) * 4
         d = _desc(N=128, H=hw, W=hw, ic=ic, oc=oc, stride=stride, mids=mids, ks=(3, 3, 5, 5) * 2, ses=(0,) * 4 + (4 * (ic // 4),) * 4)
         assert lib.tfnas_cell_plan(C.byref(d)) == 0
-        got.append((lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_fx2_supported(C.byref(d)), lib.tfnas_fxp_supported(C.byref(d))))
+        got.append((lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_fxp_supported(C.byref(d))))
     fx = [int(6 <= i <= 16 and i != 13 or i == 17) for i in range(18)]          # stride 1, 14 x 14 / 7 x 7, 64 <= ic <= 192
-    fx2 = [int(i in (0, 2)) for i in range(18)]                                   # stride 2, ic <= 24
     fxp = [int(i >= 5 and i != 17) for i in range(18)]                           # <= 14 x 14 OUTPUT pixels, oc <= 256
-    assert [g[0] for g in got] == fx and [g[1] for g in got] == fx2 and [g[2] for g in got] == fxp
+    assert [g[0] for g in got] == fx and [g[1] for g in got] == fxp
     # trainable weights: the fused expand / depthwise routes are refused (their weight gradients need E), the project dgrad is not
     d = _desc(N=128, H=14, W=14, ic=112, oc=112, mids=(336, 672) * 4, ks=(3, 3, 5, 5) * 2, ses=(0,) * 8)
     lib.tfnas_cell_plan(C.byref(d))
     d.need_wgrad = 1
     assert (lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_fxp_supported(C.byref(d))) == (0, 1)
-    # unknown flag bits are refused by the plan, the variant bits are accepted
+    # unknown flag bits are refused by the plan, the variant bit is accepted
     d = _desc()
-    d.flags = _lib.CELL_FX2 | _lib.CELL_FXP | _lib.CELL_LAZY_JOIN
+    d.flags = _lib.CELL_FXP | _lib.CELL_LAZY_JOIN
     assert lib.tfnas_cell_plan(C.byref(d)) == 0
-    d.flags = 8
-    assert lib.tfnas_cell_plan(C.byref(d)) == -1
+    for bad in (2, 8):
+        d.flags = bad
+        assert lib.tfnas_cell_plan(C.byref(d)) == -1
 
 
 def test_error_codes(lib):

@@ -30,30 +30,6 @@ FX_CASES = [
     (7, 64, 64, 1, 'swish', 5, 9),
     (2, 144, 144, 1, 'relu', 9, 8),
 ]
-# the stride-2 tiled fused forward (csrc/fx_s2.inc; tfnas_fx2_supported): the supernet's two early down-sampling cells at full
-# image size and reduced batch, + ragged extents (partial tiles in both directions, a single tile)
-FX2_CASES = [
-    (2, 16, 24, 2, 'relu', 112, 112),
-    (2, 24, 40, 2, 'swish', 56, 56),
-    (3, 24, 24, 2, 'relu', 17, 31),
-    (3, 16, 16, 2, 'swish', 9, 13),
-    (2, 16, 16, 2, 'swish', 58, 30),
-]
-
-
-def _want_fx2(m, case):
-    """FX2_CASES run with the model-level switch of the variant (HipModes.fx2 -> TFNAS_CELL_FX2 on every descriptor)."""
-    if case not in FX2_CASES:
-        return
-    import ctypes as C
-    from tfnas_amd import _lib, functions as F
-    F.adopt_modes(m, F.HipModes(fx2=True))
-    plan = m._plan(tuple(range(8)))
-    d, _ = plan.desc(case[0], case[5], case[6])
-    plan.bind(d, plan.params())
-    assert d.flags & _lib.CELL_FX2 and _lib.lib().tfnas_fx2_supported(C.byref(d)) == 1
-
-
 def _run(m, x, r, e, idxs, efree):
     from tfnas_amd import functions as F
     from tfnas_amd.functions import MixedOpFn
@@ -75,13 +51,12 @@ def _run(m, x, r, e, idxs, efree):
         F.EFREE, F.EFREE_STRIDE1 = old
 
 
-@pytest.mark.parametrize('case', CASES + FX_CASES + FX2_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
+@pytest.mark.parametrize('case', CASES + FX_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
 @pytest.mark.parametrize('idxs', [list(range(8)), [2], [5]], ids=['soft', 'op2', 'op5'])
 def test_efree_matches_e_path(case, idxs):
     N, ic, oc, stride, act, H, W = case
     mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
     o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=ic + stride)
-    _want_fx2(m, case)
     g = torch.Generator().manual_seed(7 * ic + H)
     x = torch.randn(N, ic, H, W, generator=g) * 1.5 + 0.7          # non-zero channel means: the Gram path must centre
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -110,12 +85,11 @@ def test_efree_matches_e_path(case, idxs):
         assert err <= 2e-5 + 2e-4 * ref, (name, err, ref)
 
 
-@pytest.mark.parametrize('case', CASES[:5] + FX_CASES + FX2_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
+@pytest.mark.parametrize('case', CASES[:5] + FX_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
 def test_efree_matches_oracle_stage_by_stage(case):
     N, ic, oc, stride, act, H, W = case
     mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
     o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=3)
-    _want_fx2(m, case)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, ic, H, W, generator=g) + 0.3
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -125,8 +99,8 @@ def test_efree_matches_oracle_stage_by_stage(case):
     old = F.EFREE_STRIDE1
     F.EFREE_STRIDE1 = True
     try:
-        if case in FX_CASES or (stride == 2 and ic <= 24):
-            # (recompute mode of the fused routes: the first ReLU's decisions are not observable -> compared outside the oracle's
+        if case in FX_CASES:
+            # (recompute mode of the fused route: the first ReLU's decisions are not observable -> compared outside the oracle's
             #  near-kink elements, the mask validated against an fp64 run: _hipcheck.check_cell)
             res = hc.check_cell(o, m, x, r, e, list(range(8)), False)
         else:
@@ -209,27 +183,6 @@ def test_efree_is_refused_when_unsupported():
     rc = _lib.lib().tfnas_mixedop_fwd(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(bufs[0]), _lib.ptr(bufs[1]),
                                       _lib.ptr(bufs[2]), _lib.ptr(stats), _lib.ptr(part), _lib.ptr(out), None)
     assert rc != 0
-
-
-def test_fx2_route_is_taken_by_the_down_sampling_cells():
-    """tfnas_fx2_supported: stride 2 with ic <= 24 and candidates wider than 32 mid channels; narrower candidates, wider inputs
-    and trainable weights stay on the E-free tile kernels."""
-    import ctypes as C
-    from tfnas_amd import _lib
-
-    def q(ic, stride, mids, H=20, W=28, wgrad=False):
-        o, m = hc.make_cell_pair(ic, 24, stride, 'swish', mids, seed=3)
-        plan = m._plan(tuple(range(8)))
-        d, ws = plan.desc(2, H, W)
-        plan.bind(d, plan.params())
-        d.need_wgrad = int(wgrad)
-        return _lib.lib().tfnas_fx2_supported(C.byref(d))
-
-    assert q(16, 2, [48, 96] * 4) == 1 and q(24, 2, [72, 144] * 4) == 1
-    assert q(16, 2, [48, 96] * 4, wgrad=True) == 0
-    assert q(16, 1, [48, 96] * 4) == 0
-    assert q(16, 2, [32, 96] * 4) == 0          # a one-chunk candidate
-    assert q(40, 2, [120, 240] * 4) == 0
 
 
 def test_fx_cells_keep_an_e_buffer_by_default():

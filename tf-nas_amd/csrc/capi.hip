@@ -168,7 +168,7 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
         const int gm = d->gemm_mode & ~(TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_EVERYWHERE);
         if (!(d->gemm_mode & TFNAS_GEMM_EXPLICIT) || (gm != 0 && gm != 1 && gm != 3 && gm != 6)) return TFNAS_EINVAL;
     }
-    if (d->flags & ~(TFNAS_CELL_LAZY_JOIN | TFNAS_CELL_FX2 | TFNAS_CELL_FXP)) return TFNAS_EINVAL;
+    if (d->flags & ~(TFNAS_CELL_LAZY_JOIN | TFNAS_CELL_FXP)) return TFNAS_EINVAL;
     if (d->sync_fn && d->sync_world < 1) return TFNAS_ERANGE;
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
@@ -245,7 +245,6 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     } while (0)
 
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
-extern "C" int tfnas_fx2_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp) && fx2_supported(*dp)) ? 1 : 0; }
 extern "C" int tfnas_fxp_supported(const TfnasCellDesc* dp) { return (dp && fxp_supported(*dp, (size_t)1 << 40)) ? 1 : 0; }
 extern "C" int tfnas_fx_supported(const TfnasCellDesc* dp) {
     return (dp && dp->mode == TFNAS_MODE_CELL && !dp->need_wgrad && !efree_ic_small(dp->ic) && fx_supported(*dp)) ? 1 : 0;
@@ -291,7 +290,6 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
     if (sync) TRY(stats_sync(d, stats1, 2 * (size_t)d.M, s));                    // sync-stats: global-batch sums (no-op without a hook)
     if (bn) TRY(bn_fwd_fix(d0, bn, 0, stats1, s));
     if (fx) TRY(launch_fx_fwd(d, b.x, stats1, b.E, b.D, stats2, b.part, s));  // expand + BN1 + act + depthwise in one kernel
-    else if (!b.E && !bn && fx2_wanted(d) && fx2_supported(d)) TRY(launch_fx2_fwd(d, b.x, stats1, b.D, stats2, b.part, s));   // stride 2, tiled
     else TRY(launch_dw_fwd(d, b.E, b.x, stats1, b.D, stats2, b.part, s));     // BN1+act fused load, depthwise, BN2 statistics
     if (sync) TRY(stats_sync(d, stats2, 2 * (size_t)d.M, s));
     if (bn) TRY(bn_fwd_fix(d0, bn, 1, stats2, s));

@@ -681,8 +681,6 @@ __global__ __launch_bounds__(FX_THREADS) void k_fx_fwd(TfnasCellDesc d, FxPlan p
     else fx_fwd_body<5, ACT, KS, RT>(d, pl, x, blob, D, part, fx_lds, ig, sl, Eg);
 }
 
-#include "fx_s2.inc"
-
 // ---------------------------------------------------------------------------------------------------------------- backward
 // One stencil item per thread (4-pixel strip x channel quad), the same for every chunk: worked out once.
 struct FxItem {
@@ -1485,59 +1483,6 @@ static bool fx_enabled() {
         return e ? e[0] != '0' : TFNAS_FX_DEFAULT != 0;
     }();
     return on;
-}
-
-// stride-2 tiled forward (fx_s2.inc): E-free launches of the early down-sampling cells that carry TFNAS_CELL_FX2, or all of them
-// with TFNAS_FX2 = 1 (default 0): measured
-// SLOWER than the E-free tile kernel (cell 0: 1.75 vs 1.36 ms, cell 2: 0.74 vs 0.68 ms; DESIGN.md section 4d has the ablation),
-// kept as a tested variant
-static bool fx2_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("TFNAS_FX2");
-        return e ? e[0] != '0' : false;
-    }();
-    return on;
-}
-
-bool fx2_wanted(const TfnasCellDesc& d) { return fx2_enabled() || (d.flags & TFNAS_CELL_FX2); }
-
-bool fx2_supported(const TfnasCellDesc& d) {
-    FxPlan pl;
-    if (!fx_enabled() || !fx2_plan(d, pl)) return false;
-    if (d.ic > 24) return false;                            // (staging: 8 x-pieces per lane of waves 4..7 per tile)
-    if (fx2_lds(d, pl) > 160 * 1024) return false;
-    const size_t rows = (((size_t)d.N * 2 * d.M) + 63) & ~(size_t)63, blobs = ((size_t)pl.nchunks * pl.BLOB + 3) / 4;
-    return rows + blobs + 256 <= TFNAS_PART_FLOATS;
-}
-
-int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* D, double* stats2, float* part,
-                   hipStream_t s) {
-    FxPlan pl;
-    if (!fx2_plan(d, pl)) return TFNAS_EINVAL;
-    const size_t rows = ((size_t)d.N * 2 * d.M + 63) & ~(size_t)63;
-    u8* blob = reinterpret_cast<u8*>(part + rows);
-    {
-        ProfScope _prof(TK_SMALL, s);
-        hipLaunchKernelGGL(k_fx_pack, dim3(pl.nchunks, 4), dim3(256), 0, s, d, pl, stats1, (const double*)nullptr,
-                           (const double*)nullptr, blob);
-    }
-    const size_t shm = fx2_lds(d, pl);
-    const dim3 grid(pl.nig * pl.nslices);
-    {
-        ProfScope _prof(TK_DW_FWD, s, d.G > 2);
-        if (d.act == TFNAS_ACT_RELU) {
-            static bool attr = fx_attr_done((const void*)k_fx2_fwd<0>, 160 * 1024);
-            if (!attr) return TFNAS_EINVAL;
-            hipLaunchKernelGGL(k_fx2_fwd<0>, grid, dim3(FX_THREADS), shm, s, d, pl, x, blob, D, part);
-        } else {
-            static bool attr = fx_attr_done((const void*)k_fx2_fwd<1>, 160 * 1024);
-            if (!attr) return TFNAS_EINVAL;
-            hipLaunchKernelGGL(k_fx2_fwd<1>, grid, dim3(FX_THREADS), shm, s, d, pl, x, blob, D, part);
-        }
-    }
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
-    return launch_reduce_rows(part, d.N, 2 * d.M, 2 * (size_t)d.M, stats2, nullptr, s);
 }
 
 #include "fx_pd.inc"

@@ -74,11 +74,6 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
 // recomputing it; E == nullptr: nothing is stored, the backward rebuilds ehat from x
 int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* E, float* D, double* stats2,
                   float* part, hipStream_t s);
-// stride-2 tiled variant of the fused forward (fx_s2.inc): E-free launches (E == nullptr) of cells with stride 2, ic <= 24
-bool fx2_supported(const TfnasCellDesc& d);
-bool fx2_wanted(const TfnasCellDesc& d);      // TFNAS_CELL_FX2 on the descriptor, or TFNAS_FX2=1
-int launch_fx2_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* D, double* stats2, float* part,
-                   hipStream_t s);
 // fused per-image project dgrad (fx_pd.inc): dZ + the per-image BN2-backward tables pp / dgate (what k_bn2_pool writes) in one pass,
 // for cells with at most 14 x 14 output pixels and oc <= 256; scratch (blobs): scratch_floats floats
 bool fxp_supported(const TfnasCellDesc& d, size_t scratch_floats);

@@ -22,7 +22,7 @@ _W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e
 _G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
 
 
-GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN, CELL_FX2, CELL_FXP = 0x1000, 0x100, 1, 2, 4
+GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN, CELL_FXP = 0x1000, 0x100, 1, 4
 GEMM_MODES = {'f32': 0, 'bf16': 1, 'x2': 3, 'x3': 6}
 
 
@@ -102,7 +102,6 @@ _PROTOS = {
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_fx_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
-    'tfnas_fx2_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_fxp_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_arch_project': (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),

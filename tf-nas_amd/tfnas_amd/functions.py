@@ -85,17 +85,16 @@ class HipModes:
       lazy_join    tfnas_mbconv_bwd leaves its weight-gradient kernels on the side stream (RetrainState joins once per step)
       direct_grads the derived network's blocks write weight gradients straight into the .grad views (host-side only)
       sync         None | (function pointer, user pointer, world): cross-rank BatchNorm statistics hook of this model
-      fx2          E-free forwards of the stride-2 cells take the tiled fused kernel (a tested variant, slower: TFNAS_CELL_FX2)
       fxp          backwards of the late cells take the fused per-image project dgrad (a tested variant, equal: TFNAS_CELL_FXP)"""
 
-    def __init__(self, gemm=None, everywhere=False, lazy_join=False, direct_grads=False, sync=None, fx2=False, fxp=False):
+    def __init__(self, gemm=None, everywhere=False, lazy_join=False, direct_grads=False, sync=None, fxp=False):
         self.gemm, self.everywhere, self.lazy_join, self.direct_grads, self.sync = gemm, everywhere, lazy_join, direct_grads, sync
-        self.fx2, self.fxp = fx2, fxp
+        self.fxp = fxp
 
     def apply(self, d):
         d.gemm_mode = 0 if self.gemm is None else (_lib.GEMM_EXPLICIT | _lib.GEMM_MODES[self.gemm]
                                                    | (_lib.GEMM_EVERYWHERE if self.everywhere else 0))
-        d.flags = (_lib.CELL_LAZY_JOIN if self.lazy_join else 0) | (_lib.CELL_FX2 if self.fx2 else 0) | (_lib.CELL_FXP if self.fxp else 0)
+        d.flags = (_lib.CELL_LAZY_JOIN if self.lazy_join else 0) | (_lib.CELL_FXP if self.fxp else 0)
         if self.sync is None:
             d.sync_fn, d.sync_user, d.sync_world = None, None, 0
         else:
