@@ -1518,7 +1518,9 @@ int launch_fx_pdgrad(const TfnasCellDesc& d, const float* dout, const float* Pr,
         ProfScope _prof(TK_SMALL, s);
         hipLaunchKernelGGL(k_fxp_pack, dim3(pl.nchunks, 4), dim3(256), 0, s, d, pl, stats2, blob);
     }
-    const size_t shm = fxp_lds(d, pl);
+    // TFNAS_FXP_PADLDS=1 (timing experiment, tools/r5_occupancy.py): ask for 100 KB of LDS -> ONE workgroup per CU whatever the kernel needs
+    static const bool pad_lds = getenv("TFNAS_FXP_PADLDS") != nullptr;
+    const size_t shm = pad_lds ? (size_t)100 * 1024 : fxp_lds(d, pl);
     const dim3 grid(pl.nig * pl.nslices);
     ProfScope _prof(TK_PROJECT_DGRAD, s);
 #define FXP_L(A_, KS_, RT_)                                                                                              \
