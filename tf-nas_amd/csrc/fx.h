@@ -19,6 +19,13 @@ struct FxSlice {
 };
 constexpr int FX_MAX_SLICES = 96;
 constexpr int FX_THREADS = 512;
+// padding of a blob's plane rows (bytes): the row pitch 64 KS + FX_RS_PAD decides the bank pattern of the A-operand ds_read_b128.
+// 16: the pitch in dwords is 4 (4 KS + 1), an odd multiple of 4 -- the 16 rows a group of 16 lanes reads start in 16 different bank
+// quads.  (32, the first choice, made rows n and n + 8 share their banks: 2-way conflicts on every A-operand read, 19-28 % LDS
+// conflict cycles in the SQ counters; measured: cell 10 forward 357 -> 349 us, backward 484 -> 469; cell 15 246 -> 236, 278 -> 261.)
+#ifndef FX_RS_PAD
+#define FX_RS_PAD 16
+#endif
 
 struct FxPlan {
     int KS;            // MFMA k-steps of 32 input channels: ceil(ic / 32)
@@ -26,7 +33,7 @@ struct FxPlan {
     int RTF;           // ... forward (7 worker waves + 1 copier wave)
     int NI;            // images per workgroup
     int nig;           // image groups = ceil(N / NI)
-    int RS;            // bytes per channel row of a bf16 plane in a blob (32 * KS * 2 + 32: conflict-free ds_read_b128)
+    int RS;            // bytes per channel row of a bf16 plane in a blob (32 * KS * 2 + FX_RS_PAD: conflict-free ds_read_b128)
     int PB, WB, XB;    // blob pieces: W1 planes + BN1 constants | depthwise taps | backward extras; bytes
     int BLOB;          // blob stride (bytes, multiple of 256)
     int KMAX;          // largest depthwise kernel size in the cell (sizes the LDS image tile)

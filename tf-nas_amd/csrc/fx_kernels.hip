@@ -70,7 +70,7 @@ bool fx_plan(const TfnasCellDesc& d, FxPlan& pl, bool bwd) {
     if (NI * ((d.Wo + 3) / 4) * d.Ho > 56) return false;    // one stencil item (4-pixel strip x channel quad) per worker thread
     pl.KS = KS; pl.RT = RT; pl.RTF = RTF; pl.NI = NI;
     pl.nig = (d.N + NI - 1) / NI;
-    pl.RS = 64 * KS + 32;
+    pl.RS = 64 * KS + FX_RS_PAD;
     int kmax = 3;
     for (int g = 0; g < d.G; ++g) {
         if (d.g[g].k != 3 && d.g[g].k != 5) return false;
@@ -272,7 +272,7 @@ template <int KS, int RT, int OUT>
 __device__ __forceinline__ void fx_expand(const u8* P, const FxX<KS, RT>& X, float* tile, const int (&slot)[RT],
                                           const bool (&pv)[RT], int ntiles, float* __restrict__ eg = nullptr,
                                           const size_t* egoff = nullptr, int chlim = 0) {
-    constexpr int RS = 64 * KS + 32;
+    constexpr int RS = 64 * KS + FX_RS_PAD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     f32x4 acc[2][RT];
 #pragma unroll
@@ -401,7 +401,7 @@ __device__ __forceinline__ void fx_fwd_interval(const u8* P, const FxX<KS, RT>& 
                                                 const bool (&pv)[RT], float* __restrict__ eg, const size_t* egoff, bool do_expand,
                                                 const float* tile, const float* taps, const FxFItem it, int WP, int M, bool chok,
                                                 float* __restrict__ Dc, float* stat) {
-    constexpr int RS = 64 * KS + 32;
+    constexpr int RS = 64 * KS + FX_RS_PAD;
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, cq = lane & 7;
     f32x4 acc[2][RT];
 #pragma unroll
@@ -503,7 +503,7 @@ template <int K, int ACT, int KS, int RT>
 __device__ __forceinline__ void fx_fwd_body(const TfnasCellDesc& d, const FxPlan& pl, const float* __restrict__ x,
                                             const u8* __restrict__ blob, float* __restrict__ D, float* __restrict__ part,
                                             u8* lds, int ig, const FxSlice sl, float* __restrict__ Eg) {
-    constexpr int PAD = K / 2, RS = 64 * KS + 32, PB = 96 * RS + 256, WBK = K * K * 128;
+    constexpr int PAD = K / 2, RS = 64 * KS + FX_RS_PAD, PB = 96 * RS + 256, WBK = K * K * 128;
     constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
     constexpr int NCP = (PB + 1023) / 1024, NCW = (WBK + 1023) / 1024;      // copier: 1 KiB per wave instruction
     constexpr int NCP1 = NCP < 28 ? NCP : 28;                               // pieces held in registers across the barrier
@@ -758,7 +758,7 @@ __device__ __forceinline__ void fx_bwd_body(const TfnasCellDesc& d, const FxPlan
                                             const float* __restrict__ Dt, const float* __restrict__ gate,
                                             const float* __restrict__ dpooled, float* __restrict__ dxp,
                                             float* __restrict__ part, u8* lds, int ig, const FxSlice sl, int si) {
-    constexpr int KS = (CT + 1) / 2, PAD = K / 2, RS = 64 * KS + 32, PB = 96 * RS + 256, WBK = K * K * 128, WRB = 3 * CT * 16 * 64;
+    constexpr int KS = (CT + 1) / 2, PAD = K / 2, RS = 64 * KS + FX_RS_PAD, PB = 96 * RS + 256, WBK = K * K * 128, WRB = 3 * CT * 16 * 64;
     constexpr int NVP = (PB + FX_THREADS * 16 - 1) / (FX_THREADS * 16), NVR = (WRB + FX_THREADS * 16 - 1) / (FX_THREADS * 16);
     constexpr int NR = 2 * RT;                       // rounds of the dd loader: 128 RT pixels x 8 quads / 512 threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4, cq = tid & 7;
