@@ -21,8 +21,9 @@ constexpr int FX_MAX_SLICES = 96;
 constexpr int FX_THREADS = 512;
 // padding of a blob's plane rows (bytes): the row pitch 64 KS + FX_RS_PAD decides the bank pattern of the A-operand ds_read_b128.
 // 16: the pitch in dwords is 4 (4 KS + 1), an odd multiple of 4 -- the 16 rows a group of 16 lanes reads start in 16 different bank
-// quads.  (32, the first choice, made rows n and n + 8 share their banks: 2-way conflicts on every A-operand read, 19-28 % LDS
-// conflict cycles in the SQ counters; measured: cell 10 forward 357 -> 349 us, backward 484 -> 469; cell 15 246 -> 236, 278 -> 261.)
+// quads; with 32, the first choice, rows n and n + 8 share their banks.  Measured (two alternating A/B runs on one box): -2 % on the
+// KS = 4 cells (cell 10 / 12: forward 0.372 -> 0.367 / 0.343 -> 0.335 ms, backward 0.511 -> 0.499 / 0.461 -> 0.451), +-0 at KS = 3 and
+// KS = 6 -- while the SQ counters of the forward show MORE conflict cycles (0.28 -> 0.37 of the LDS cycles): the clock decides.
 #ifndef FX_RS_PAD
 #define FX_RS_PAD 16
 #endif
