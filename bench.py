@@ -132,7 +132,7 @@ def family_algorithmic(fam, B, mode=None):
                 if fam == 'k_project_wgrad':
                     f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + 2 * Po * oc)
                 elif fam == 'k_expand_wgrad':
-                    f, b = 2.0 * P * M * ic, 4.0 * (2 * P * M + P * ic)
+                    f, b = 2.0 * P * M * ic, 4.0 * (P * M + P * ic)     # Gram form: dEh and x, E is not read
                 else:
                     f, b = 2.0 * Po * M * 17.0, 4.0 * (2 * Po * M + P * M)
             else:

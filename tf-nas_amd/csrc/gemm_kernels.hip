@@ -920,14 +920,22 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
 }
 
 // ============================================================================ expand wgrad (TN, split-K)
-// part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]   (k_reduce_rows sums the splits)
-template <int NT, bool STEM>
+// XG = false (stem; TFNAS_XG=0):  part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]  with the
+//   BN1-backward operand de = rstd (deh - t1 - ehat t2) formed per element from dEh AND E (k_reduce_rows sums the splits).
+// XG = true (default): E is not read.  E is linear in x (E[p][m] = sum_c' W[m][c'] x[p][c']), so
+//   sum_p de[p][m] x[p][c] = r_m ( R[m][c] - t1_m sx[c] - t2_m r_m ( (W Gx)[m][c] - mu_m sx[c] ) ),
+//   R = sum_p deh x^T,  Gx = sum_p x x^T (ic x ic),  sx = sum_p x,  (mu, r, t1, t2) = cb1[m]
+// and the kernel streams ONE [P][M] tensor with plain loads: the rows of R, and -- as ic + 1 more "mid channels" behind the
+// last group's rows (operand = x itself / the constant 1) -- the rows of Gx | sx.  k_reduce_rows sums the splits in double,
+// k_expand_wgrad_fix applies the formula in double (autograd of inverted_bottleneck.conv + BatchNorm2d, layers.py:463-482).
+template <int NT, bool STEM, bool XG>
 __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDesc d, const float* __restrict__ dEh,
                                                       const float* __restrict__ E, const float* __restrict__ cb1,
                                                       const float* __restrict__ x, int rows_per_split,
-                                                      float* __restrict__ part, size_t out_size) {
+                                                      float* __restrict__ part, size_t out_size, size_t out_main) {
     using T = GT<NT>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
+    const int ic = d.ic;
     int ty = blockIdx.y, g = 0;
     for (; g < d.G - 1; ++g) {
         const int t = (d.g[g].mcp + 127) >> 7;
@@ -935,11 +943,13 @@ __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDes
         ty -= t;
     }
     const int mc = d.g[g].mc, mcp = d.g[g].mcp, off = d.g[g].off;
+    const bool last = XG && g == d.G - 1;           // the group whose row space carries the ic + 1 extension rows
     size_t poff = 0;
-    for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * d.ic;
+    for (int gg = 0; gg < g; ++gg) poff += (size_t)d.g[gg].mc * ic;
     float* __restrict__ gw = part + (size_t)blockIdx.x * out_size + poff;
+    float* __restrict__ gx = part + (size_t)blockIdx.x * out_size + out_main;
     const int m0 = ty * 128, n0 = blockIdx.z * T::BN;
-    const int P = d.N * d.H * d.W, ic = d.ic, M = d.M;
+    const int P = d.N * d.H * d.W, M = d.M;
     const int r0 = blockIdx.x * rows_per_split, r1 = min(P, r0 + rows_per_split);
     const int nchunks = (r1 - r0 + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4, wrow = (tid >> 6) * 32;
@@ -949,15 +959,23 @@ __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDes
     const int mch = m0 + (tid & 31) * 4;
     const bool chok = mch < mcp;
     const size_t acol = (size_t)off + min(mch, mcp - 4);
-    f32x4 k_mu, k_r, k_rt1, k_s;
+    f32x4 k_mu = zero4(), k_r = zero4(), k_rt1 = zero4(), k_s = zero4();
+    if (!XG) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 t = (mch + j < mcp) ? reinterpret_cast<const f32x4*>(cb1)[off + mch + j] : zero4();
-        k_mu[j] = t.x;
-        k_r[j] = t.y;
-        k_rt1[j] = t.y * t.z;
-        k_s[j] = t.y * t.y * t.w;
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = (mch + j < mcp) ? reinterpret_cast<const f32x4*>(cb1)[off + mch + j] : zero4();
+            k_mu[j] = t.x;
+            k_r[j] = t.y;
+            k_rt1[j] = t.y * t.z;
+            k_s[j] = t.y * t.y * t.w;
+        }
     }
+    // XG: one base pointer and row pitch per thread -- its quad of dEh columns, or (extension rows) its quad of x columns
+    const int ext = mch - mcp;                       // >= 0: extension row (x channel `ext`; ext == ic: the constant 1)
+    const bool ax = last && ext >= 0 && ext < ic, aone = last && ext == ic;
+    const float* __restrict__ abase = ax ? x + ext : dEh + acol;
+    const size_t apitch = ax ? (size_t)ic : (size_t)M;
+    const bool aok = chok || ax;
     constexpr int BQ = T::BN / 4;
     int bcol[T::B_ITERS];
     bool bok[T::B_ITERS];
@@ -972,13 +990,23 @@ __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDes
     acc_zero<NT>(acc);
     auto la = [&](int c, int i, int kl, int m) -> Raw2 {
         const int p = min(r0 + c * 16 + kl, r1 - 1);
-        const size_t at = (size_t)p * M + acol;
         Raw2 r;
-        r.a = ldS4_raw(dEh, at, d.stor);
-        r.b = ldS4_raw(E, at, d.stor);
+        if (XG) {
+            r.a = ld4(abase + (size_t)p * apitch);
+            r.b = r.a;
+        } else {
+            const size_t at = (size_t)p * M + acol;
+            r.a = ldS4_raw(dEh, at, d.stor);
+            r.b = ldS4_raw(E, at, d.stor);
+        }
         return r;
     };
     auto xa = [&](Raw2 r, int c, int i, int kl, int m) -> f32x4 {
+        if (XG) {
+            f32x4 v = aok ? r.a : zero4();
+            if (aone) v.x = 1.f;
+            return (r0 + c * 16 + kl < r1) ? v : zero4();
+        }
         const f32x4 v = (k_r * ldS4_fin(r.a, d.stor) - k_rt1) - (ldS4_fin(r.b, d.stor) - k_mu) * k_s;
         return (chok && r0 + c * 16 + kl < r1) ? v : zero4();
     };
@@ -1000,14 +1028,45 @@ __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDes
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ch = m0 + wrow + 16 * i + 4 * lq + r;
-            if (ch < mc) {
+            float* __restrict__ row = nullptr;
+            if (ch < mc) row = gw + (size_t)ch * ic;
+            else if (last && ch >= mcp && ch - mcp <= ic) row = gx + (size_t)(ch - mcp) * ic;
+            if (row) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int cc = n0 + 16 * j + lr;
-                    if (cc < ic) gw[(size_t)ch * ic + cc] = acc[i][j][r];
+                    if (cc < ic) row[cc] = acc[i][j][r];
                 }
             }
         }
+}
+
+// red: the split sums of k_expand_wgrad<XG> in double -- R of every group | Gx [ic][ic] | sx [ic]
+//   g_expand_g[m][c] = r ( R - t1 sx[c] - t2 r ( sum_c' W[m][c'] Gx[c'][c] - mu sx[c] ) ),   (mu, r, t1, t2) = cb1[off_g + m]
+__global__ __launch_bounds__(256) void k_expand_wgrad_fix(TfnasCellDesc d, const float* __restrict__ cb1,
+                                                          const double* __restrict__ red, size_t out_main) {
+    const int ic = d.ic;
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= out_main) return;
+    int g = 0;
+    size_t poff = 0;
+    for (; g < d.G - 1; ++g) {
+        const size_t n = (size_t)d.g[g].mc * ic;
+        if (e < poff + n) break;
+        poff += n;
+    }
+    const int m = (int)((e - poff) / ic), c = (int)(e - poff - (size_t)m * ic);
+    const f32x4 t = reinterpret_cast<const f32x4*>(cb1)[d.g[g].off + m];
+    const double* __restrict__ Gx = red + out_main;
+    const double sx = Gx[(size_t)ic * ic + c];
+    const float* __restrict__ w = d.g[g].w_expand + (size_t)m * ic;
+    double wg0 = 0.0, wg1 = 0.0;
+    for (int k = 0; k < ic; k += 2) {                  // ic % 4 == 0 (cells; the stem keeps the per-element form)
+        wg0 += (double)w[k] * Gx[(size_t)k * ic + c];
+        wg1 += (double)w[k + 1] * Gx[(size_t)(k + 1) * ic + c];
+    }
+    const double mu = t.x, r = t.y, t1 = t.z, t2 = t.w;
+    d.g[g].g_expand[e - poff] = (float)(r * (red[e] - t1 * sx - t2 * r * ((wg0 + wg1) - mu * sx)));
 }
 
 // ============================================================================ host launchers
@@ -1240,13 +1299,13 @@ int launch_project_dgrad(const TfnasCellDesc& d, const float* dout, const float*
     return (int)hipGetLastError();
 }
 
-static int pick_rows_per_split(int rows, int out_tiles, size_t out_size, int nt) {
+static int pick_rows_per_split(int rows, int out_tiles, size_t out_size, int nt, size_t scratch = TFNAS_PART_FLOATS) {
     // ONE resident round: as many workgroups as the chip holds of this variant (256 CUs x wgrad_lb), never a second, mostly
     // empty round (cell 10: 55 splits x 6 tiles = 330 workgroups on 256 slots ran 2 x 65 us); at least 128 rows (8 K-chunks)
     // per split; partial tiles must fit the scratch
     const int target = 256 * wgrad_lb(nt), min_rows = 128;
     int splits = target / (out_tiles > 0 ? out_tiles : 1);
-    const size_t cap = TFNAS_PART_FLOATS / (out_size > 0 ? out_size : 1);
+    const size_t cap = scratch / (out_size > 0 ? out_size : 1);
     if ((size_t)splits > cap) splits = (int)cap;
     if (splits < 1) splits = 1;
     int rps = cdiv(rows, splits);
@@ -1373,25 +1432,56 @@ int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* c
     return (int)hipGetLastError();
 }
 
+// TFNAS_XG = 1 (default) | 0: expand weight gradient without reading E (Gram form, k_expand_wgrad<XG>) / from dEh and E per
+// element; both are compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
+static const bool g_expand_xg = [] {
+    const char* e = getenv("TFNAS_XG");
+    return !(e && e[0] == '0');
+}();
+
+bool expand_wgrad_needs_E(const TfnasCellDesc& d) {
+    return !(g_expand_xg && d.mode != TFNAS_MODE_STEM && (d.ic & 3) == 0);
+}
+
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s) {
     ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;
+    const bool xg = !expand_wgrad_needs_E(d);
+    if (!xg && !E) return TFNAS_ENULL;
+    const int next = xg ? d.ic + 1 : 0;                             // extension rows behind the last group's
     int mtiles = 0;
-    for (int g = 0; g < d.G; ++g) mtiles += cdiv(d.g[g].mcp, 128);
+    for (int g = 0; g < d.G; ++g) mtiles += cdiv(d.g[g].mcp + (g == d.G - 1 ? next : 0), 128);
     const int ntiles = cdiv(d.ic, 16 * nt);
-    size_t out_size = 0;
-    for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.ic;
-    const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size, nt);
+    size_t out_main = 0;
+    for (int g = 0; g < d.G; ++g) out_main += (size_t)d.g[g].mc * d.ic;
+    const size_t out_size = out_main + (size_t)next * d.ic;
+    // XG: the double sums of the splits live in the top of `part` (2 floats per element, 16-byte aligned)
+    const size_t red_floats = xg ? 2 * out_size + 4 : 0;
+    if (red_floats + out_size > TFNAS_PART_FLOATS) return TFNAS_ERANGE;
+    const int rps = pick_rows_per_split(P, mtiles * ntiles, out_size, nt, TFNAS_PART_FLOATS - red_floats);
     dim3 grid(cdiv(P, rps), mtiles, ntiles);
     DISPATCH_NT(nt, {
         if (d.mode == TFNAS_MODE_STEM)
-            hipLaunchKernelGGL((k_expand_wgrad<NT, true>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
+            hipLaunchKernelGGL((k_expand_wgrad<NT, true, false>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size,
+                               out_main);
+        else if (xg)
+            hipLaunchKernelGGL((k_expand_wgrad<NT, false, true>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size,
+                               out_main);
         else
-            hipLaunchKernelGGL((k_expand_wgrad<NT, false>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size);
+            hipLaunchKernelGGL((k_expand_wgrad<NT, false, false>), grid, dim3(256), 0, s, d, dEh, E, cb1, x, rps, part, out_size,
+                               out_main);
     })
     _prof.stop();
+    if (xg) {
+        double* red = reinterpret_cast<double*>((uintptr_t)(part + TFNAS_PART_FLOATS - red_floats + 3) & ~(uintptr_t)15);
+        int rc = launch_reduce_rows(part, grid.x, (int)out_size, out_size, red, nullptr, s);
+        if (rc) return rc;
+        ProfScope _p2(TK_EXPAND_WGRAD, s);
+        hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 256)), dim3(256), 0, s, d, cb1, red, out_main);
+        return (int)hipGetLastError();
+    }
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {
         const int n = d.g[g].mc * d.ic;
