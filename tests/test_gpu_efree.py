@@ -111,38 +111,6 @@ def test_efree_matches_oracle_stage_by_stage(case):
     assert not hc.worst(res), hc.worst(res)
 
 
-@pytest.mark.parametrize('case', CASES[:5], ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
-@pytest.mark.parametrize('idx', [1, 4, 7])
-def test_efree_with_weight_gradients_matches_oracle_and_e_path(case, idx):
-    """The w-step's launches of the narrow early cells: E is never materialised although the weights want gradients -- the expand
-    weight gradient comes from its Gram form (k_expand_wgrad<XG>: dEh and x only), the depthwise one from a tile recomputed from
-    x (k_dw_wgrad<.., KQ>).  Stage by stage against the oracle, and weight gradients against the materialised route."""
-    N, ic, oc, stride, act, H, W = case
-    mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
-    o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=5)
-    g = torch.Generator().manual_seed(13)
-    x = torch.randn(N, ic, H, W, generator=g) * 1.3 + 0.4          # non-zero channel means: the Gram form must cancel them
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    r = torch.randn(N, oc, Ho, Wo, generator=g)
-    e = torch.empty(8).exponential_(generator=g)
-    from tfnas_amd import functions as F
-
-    def grads(efree_w):
-        old = (F.EFREE_STRIDE1, F.EFREE_W)
-        F.EFREE_STRIDE1, F.EFREE_W = True, efree_w
-        try:
-            res = hc.check_cell(o, m, x, r, e, [idx], True)
-        finally:
-            F.EFREE_STRIDE1, F.EFREE_W = old
-        return res
-    r1 = grads(True)
-    assert not any(k.endswith('.E') for k in r1), sorted(r1)               # the E-free route was taken
-    assert not hc.worst(r1), hc.worst(r1)
-    r0 = grads(False)
-    assert any(k.endswith('.E') for k in r0)                               # ... and the switch restores the materialised one
-    assert not hc.worst(r0), hc.worst(r0)
-
-
 @pytest.mark.parametrize('case', FX_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
 @pytest.mark.parametrize('idxs', [list(range(8)), [6]], ids=['soft', 'op6'])
 def test_fx_stored_ehat_mode_matches_oracle_stage_by_stage(case, idxs):

@@ -425,7 +425,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         if (d.SE > 0 || !dw_fused) {
             hipStream_t sw = fork_to(so, 1, s);
             if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
-            if (!dw_fused) TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw, b.x));
+            if (!dw_fused) TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
         }
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table

@@ -448,14 +448,11 @@ __global__ __launch_bounds__(256, 4) void k_dw_bwd_data(TfnasCellDesc d, const f
 // ============================================================================ weight gradient
 // part[bx][poff_g + c*K*K + ky*K + kx] = sum over this workgroup's tiles of dd[n][ho][wo][c] * a1[n][ho*S+ky-p][wo*S+kx-p][c]
 // (a1 = act(BN1(E))); k_reduce_rows sums the workgroups into g_dw
-// KQ > 0 (E-free, efree.h): the a1 tile is recomputed from the cell input x instead of being read from E (w-step of the
-// stride-2 ic <= 24 cells, where E is 300-600 MB per sampled candidate and x a sixth to a third of that).
-template <int K, int S, int ACT, int KQ>
+template <int K, int S, int ACT>
 __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const float* __restrict__ dZ,
                                                      const float* __restrict__ gate, const float* __restrict__ dpooled,
                                                      const float* __restrict__ D, const double* __restrict__ stats2,
                                                      const double* __restrict__ red2, const float* __restrict__ E,
-                                                     const float* __restrict__ x,
                                                      const double* __restrict__ stats1, float* __restrict__ part,
                                                      size_t out_size, DwGeom gm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -479,11 +476,6 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
     if (tid < CC)
         cst1[tid] = (c0 + tid < mc) ? bn_consts(stats1 + 2 * (size_t)(off + c0 + tid), 1.0 / ((double)d.N * H * W), d.eps)
                                     : make_float2(0.f, 0.f);
-    ExpandB<(KQ > 0 ? KQ : 2)> xb;
-    if (KQ > 0) {
-        __syncthreads();
-        expand_b_load(xb, d.g[g].w_expand, d.ic, c0, mc, cst1);
-    }
 
     constexpr int WIN = 3 * S + K;
     const int nsw = TW >> 2, nstrips = TH * nsw;
@@ -523,15 +515,6 @@ __global__ __launch_bounds__(256, 2) void k_dw_wgrad(TfnasCellDesc d, const floa
         bool pok[4] = {false, false, false, false};
         if (tid < nitems) item_ops(tid, pdd, pdv, pok);
         __syncthreads();
-        if (KQ > 0) {
-            const float inv_iw = 1.f / (float)IW;
-            expand_tile<(KQ > 0 ? KQ : 2), ACT>(in_tile, IH * IW, CC, x, xb, [&](int p, size_t& a) {
-                const int r = (int)(((float)p + 0.5f) * inv_iw), c = p - r * IW;
-                const int hi = hi0 + r, wi = wi0 + c;
-                a = ((size_t)(n * H + hi) * W + wi) * d.ic;
-                return hi >= 0 && hi < H && wi >= 0 && wi < W;
-            });
-        } else
         load_tile(in_tile, IH, IW, CC, gm.cq_shift, E,
                   [&](int r, int c, int cq, size_t& a) {
                       const int hi = hi0 + r, wi = wi0 + c;
@@ -734,19 +717,15 @@ static int launch_dw_bwd_data_tiled(const TfnasCellDesc& d, const float* dZ, con
     return launch_reduce_rows(part, gx, 2 * d.M, 2 * (size_t)d.M, red1, nullptr, s);
 }
 
-// E == nullptr: E-free mode (the a1 tile is recomputed from x, efree.h)
 static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
                     const double* stats2,
-                    const double* red2, const float* E, const float* x, const double* stats1, float* part, hipStream_t s) {
-    const bool ef = E == nullptr;
-    if (ef && (!x || !efree_ic_ok(d.ic))) return TFNAS_EINVAL;
-    const int kq = ef ? d.ic / 4 : 0;
+                    const double* red2, const float* E, const double* stats1, float* part, hipStream_t s) {
     size_t out_size = 0;
     for (int g = 0; g < d.G; ++g) out_size += (size_t)d.g[g].mc * d.g[g].k * d.g[g].k;
-    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 2048, out_size, ef);
+    const int gx = dw_common_gx(d, d.Ho, d.Wo, true, 2048, out_size);
     for (int kk = 3; kk <= 5; kk += 2) {
         DwGeom gm;
-        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm, ef);
+        pick_tile(d.N, d.Ho, d.Wo, kk, d.stride, true, gm);
         const int chunks = dw_chunks(d, kk, gm.CC);
         if (!chunks) continue;
         int tile = gm.L0 * gm.L1 * gm.CC;
@@ -754,11 +733,10 @@ static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const 
         const size_t shm = (size_t)(tile + 4 * gm.CC + 2 * gm.CC) * sizeof(float);
         dim3 grid(gx, chunks);
         ProfScope _prof(TK_DW_WGRAD, s);
-        if ((size_t)shm > 64 * 1024) return TFNAS_ERANGE;
-        DW_DISPATCH(kk, d.stride, d.act, KQ_DISPATCH(kq, {
-            hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT, KQ>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E, x,
-                               stats1, part, out_size, gm);
-        }))
+        DW_DISPATCH(kk, d.stride, d.act, {
+            hipLaunchKernelGGL((k_dw_wgrad<K, S, ACT>), grid, dim3(256), shm, s, d, dZ, gate, dpooled, D, stats2, red2, E, stats1,
+                               part, out_size, gm);
+        })
     }
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {

@@ -134,10 +134,8 @@ __global__ __launch_bounds__(256) void k_stats1_gram(TfnasCellDesc d, const doub
 }
 
 bool efree_supported(const TfnasCellDesc& d) {
-    if (d.mode != TFNAS_MODE_CELL) return false;
-    if (!efree_ic_ok(d.ic)) return !d.need_wgrad && fx_supported(d);   // late cells: the fused per-image route (fx_kernels.hip)
-    // weight gradients without E: the expand one in its Gram form (k_expand_wgrad<XG>), the depthwise one from a recomputed tile
-    if (d.need_wgrad && expand_wgrad_needs_E(d)) return false;
+    if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
+    if (!efree_ic_ok(d.ic)) return fx_supported(d);            // late cells: the fused per-image route (fx_kernels.hip)
     if (stats_sync_on(d)) return false;          // (cross-rank statistics are reduced on the (sum, sumsq) tables of E)
     if ((size_t)d.N * d.H * d.W * d.ic >= ((size_t)1 << 31)) return false;
     for (int g = 0; g < d.G; ++g)

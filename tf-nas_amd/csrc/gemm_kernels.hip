@@ -1043,11 +1043,14 @@ __global__ __launch_bounds__(256, wgrad_lb(NT)) void k_expand_wgrad(TfnasCellDes
 
 // red: the split sums of k_expand_wgrad<XG> in double -- R of every group | Gx [ic][ic] | sx [ic]
 //   g_expand_g[m][c] = r ( R - t1 sx[c] - t2 r ( sum_c' W[m][c'] Gx[c'][c] - mu sx[c] ) ),   (mu, r, t1, t2) = cb1[off_g + m]
+// A workgroup owns 64 consecutive outputs; the four waves take interleaved quarters of the c' sum (combined through LDS in
+// wave order: bit-reproducible).
 __global__ __launch_bounds__(256) void k_expand_wgrad_fix(TfnasCellDesc d, const float* __restrict__ cb1,
                                                           const double* __restrict__ red, size_t out_main) {
-    const int ic = d.ic;
-    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= out_main) return;
+    __shared__ double ps[4][64];
+    const int ic = d.ic, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + lane;
+    const bool ok = e < out_main;
     int g = 0;
     size_t poff = 0;
     for (; g < d.G - 1; ++g) {
@@ -1055,18 +1058,23 @@ __global__ __launch_bounds__(256) void k_expand_wgrad_fix(TfnasCellDesc d, const
         if (e < poff + n) break;
         poff += n;
     }
-    const int m = (int)((e - poff) / ic), c = (int)(e - poff - (size_t)m * ic);
-    const f32x4 t = reinterpret_cast<const f32x4*>(cb1)[d.g[g].off + m];
+    const int m = ok ? (int)((e - poff) / ic) : 0, c = ok ? (int)(e - poff - (size_t)m * ic) : 0;
     const double* __restrict__ Gx = red + out_main;
-    const double sx = Gx[(size_t)ic * ic + c];
     const float* __restrict__ w = d.g[g].w_expand + (size_t)m * ic;
     double wg0 = 0.0, wg1 = 0.0;
-    for (int k = 0; k < ic; k += 2) {                  // ic % 4 == 0 (cells; the stem keeps the per-element form)
-        wg0 += (double)w[k] * Gx[(size_t)k * ic + c];
-        wg1 += (double)w[k + 1] * Gx[(size_t)(k + 1) * ic + c];
+    for (int k = 4 * wv; k < ic; k += 16) {            // ic % 4 == 0 (cells; the stem keeps the per-element form)
+        const f32x4 wq = ld4(w + k);
+        wg0 += (double)wq.x * Gx[(size_t)k * ic + c] + (double)wq.z * Gx[(size_t)(k + 2) * ic + c];
+        wg1 += (double)wq.y * Gx[(size_t)(k + 1) * ic + c] + (double)wq.w * Gx[(size_t)(k + 3) * ic + c];
     }
-    const double mu = t.x, r = t.y, t1 = t.z, t2 = t.w;
-    d.g[g].g_expand[e - poff] = (float)(r * (red[e] - t1 * sx - t2 * r * ((wg0 + wg1) - mu * sx)));
+    ps[wv][lane] = wg0 + wg1;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const double wg = (ps[0][lane] + ps[1][lane]) + (ps[2][lane] + ps[3][lane]);
+        const f32x4 t = reinterpret_cast<const f32x4*>(cb1)[d.g[g].off + m];
+        const double sx = Gx[(size_t)ic * ic + c], mu = t.x, r = t.y, t1 = t.z, t2 = t.w;
+        d.g[g].g_expand[e - poff] = (float)(r * (red[e] - t1 * sx - t2 * r * (wg - mu * sx)));
+    }
 }
 
 // ============================================================================ host launchers
@@ -1432,15 +1440,17 @@ int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* c
     return (int)hipGetLastError();
 }
 
-// TFNAS_XG = 1 (default) | 0: expand weight gradient without reading E (Gram form, k_expand_wgrad<XG>) / from dEh and E per
-// element; both are compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
-static const bool g_expand_xg = [] {
+// TFNAS_XG = auto (default) | 0 | all: expand weight gradient without reading E (Gram form, k_expand_wgrad<XG>) where E is at
+// least 100 MB (measured alone at B = 128, tools/r5_xg.sh: cell 0 0.33 -> 0.24 ms, cells 1 / 2 equal; from 28 x 28 on E comes
+// from the last-level cache and the extension rows + the fix-up launch cost more than the second stream: cell 10 0.08 -> 0.11 ms)
+// / never / wherever the shape allows (tests); every choice is compared with the oracle (tests/test_gpu_cell.py)
+static const int g_expand_xg = [] {
     const char* e = getenv("TFNAS_XG");
-    return !(e && e[0] == '0');
+    return !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "all") ? 2 : 1));
 }();
-
-bool expand_wgrad_needs_E(const TfnasCellDesc& d) {
-    return !(g_expand_xg && d.mode != TFNAS_MODE_STEM && (d.ic & 3) == 0);
+static bool expand_wgrad_xg(const TfnasCellDesc& d) {
+    if (!g_expand_xg || d.mode == TFNAS_MODE_STEM || (d.ic & 3) != 0) return false;
+    return g_expand_xg == 2 || (size_t)d.N * d.H * d.W * d.M * sizeof(float) >= ((size_t)100 << 20);
 }
 
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
@@ -1448,7 +1458,7 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
     ProfScope _prof(TK_EXPAND_WGRAD, s);
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int P = d.N * d.H * d.W;
-    const bool xg = !expand_wgrad_needs_E(d);
+    const bool xg = expand_wgrad_xg(d);
     if (!xg && !E) return TFNAS_ENULL;
     const int next = xg ? d.ic + 1 : 0;                             // extension rows behind the last group's
     int mtiles = 0;
@@ -1479,7 +1489,7 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
         int rc = launch_reduce_rows(part, grid.x, (int)out_size, out_size, red, nullptr, s);
         if (rc) return rc;
         ProfScope _p2(TK_EXPAND_WGRAD, s);
-        hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 256)), dim3(256), 0, s, d, cb1, red, out_main);
+        hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 64)), dim3(256), 0, s, d, cb1, red, out_main);
         return (int)hipGetLastError();
     }
     size_t poff = 0;

@@ -97,9 +97,7 @@ int launch_reduce_bn1(const TfnasCellDesc& d, const float* part, int nb, const d
                       hipStream_t s);
 int launch_dw_wgrad(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled, const float* D,
                     const double* stats2,
-                    const double* red2, const float* E, const double* stats1, float* part, hipStream_t s,
-                    const float* x = nullptr);           // E == nullptr: E-free (a1 recomputed from x)
-bool expand_wgrad_needs_E(const TfnasCellDesc& d);        // gemm_kernels.hip: false in the Gram form (TFNAS_XG, default)
+                    const double* red2, const float* E, const double* stats1, float* part, hipStream_t s);
 
 // pointwise_kernels.hip (SE squeeze, BN2 backward statistics, mixing epilogue, BN constant tables)
 // se_kernels.hip (SE excite FCs as small GEMMs: launch_se_fc_fwd / launch_se_fc_bwd / launch_se_wgrad)

@@ -102,7 +102,7 @@ int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
         TRY(tfnas_cell_plan(&d));
         TRY(tfnas_cell_ws(&d, &c.cws[i]));
         const bool efree = (pd.efree_mask_lo >> i) & 1;
-        if (efree && !efree_supported(d)) return TFNAS_EINVAL;
+        if (efree && (d.need_wgrad || !efree_supported(d))) return TFNAS_EINVAL;
     }
     // a stage whose input is a depth choice must keep the extent (ic == oc, stride 1 in its first cell)
     for (int st = 0; st < pd.nstage; ++st) {

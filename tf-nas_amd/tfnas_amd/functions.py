@@ -23,10 +23,6 @@ BN_EPS = 1e-5
 _EFREE_ENV = os.environ.get('TFNAS_EFREE', '1')
 EFREE = _EFREE_ENV != '0'
 EFREE_STRIDE1 = _EFREE_ENV == 'all'
-# TFNAS_EFREE_W = 0 (default) | 1: the same cells E-free in launches WITH weight gradients too (the w-step: expand weight gradient
-# in its Gram form, depthwise weight gradient from a recomputed tile).  Measured slower for one-candidate launches (w-step 17.9 ->
-# 18.5 ms, tools/r5_efw.sh): the tile kernels' recompute pays only when eight candidates share the x tile.
-EFREE_W = os.environ.get('TFNAS_EFREE_W', '0') == '1'
 # (TFNAS_FX = 1 (default) | 0 is read by the library: frozen-weight launches of the cells at 14 x 14 / 7 x 7 through the fused
 #  per-image kernels, csrc/fx_kernels.hip / through the materialised route)
 
@@ -199,7 +195,7 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     # cells never materialise the expanded tensor -- the depthwise kernels recompute it from x
     # (the late cells -- tfnas_fx_supported -- keep their E buffer: the fused per-image kernels leave ehat in it for the backward;
     #  TFNAS_EFREE=all drops it there too and the backward recomputes)
-    efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and (EFREE_W or not d.need_wgrad)
+    efree = (EFREE and ((plan.stride == 2 and plan.ic <= 24) or EFREE_STRIDE1) and not any(ctx.needs_input_grad[3:])
              and bool(_lib.lib().tfnas_efree_supported(C.byref(d))))
     E = None if efree else torch.empty(ws.E, device=dev, dtype=torch.float32)
     D = torch.empty(ws.D, device=dev, dtype=torch.float32)

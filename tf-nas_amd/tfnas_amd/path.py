@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from ._lib import TfnasCellDesc, TfnasPathDesc, TfnasPathWs, check, ptr, raw_array
-from .functions import BN_EPS, DEFAULT_MODES, EFREE, EFREE_STRIDE1, EFREE_W, _nhwc, _on, _require_cuda
+from .functions import BN_EPS, DEFAULT_MODES, EFREE, EFREE_STRIDE1, _nhwc, _on, _require_cuda
 
 ALIGN = 64          # floats; every parameter starts on a 256-byte boundary of the arenas
 
@@ -201,9 +201,8 @@ class PathRunner:
                 raise RuntimeError('tfnas_amd: weight gradients at the path level need a WeightArena that owns the weights')
             pd.cell[i] = t
             pd.cell[i].need_wgrad = int(need_wgrad)
-            if (soft or EFREE_W) and (EFREE_W or not need_wgrad) and EFREE \
-                    and ((cell.stride == 2 and cell.in_channels <= 24) or EFREE_STRIDE1) \
-                    and self.lib.tfnas_efree_supported(C.byref(pd.cell[i])):
+            if soft and not need_wgrad and EFREE and ((cell.stride == 2 and cell.in_channels <= 24) or EFREE_STRIDE1) \
+                    and self.lib.tfnas_efree_supported(C.byref(t)):
                 mask |= 1 << i
             h, w = (h - 1) // cell.stride + 1, (w - 1) // cell.stride + 1
         pd.efree_mask_lo = mask
