@@ -149,6 +149,7 @@ VARIANTS = {            # name: (environment, shapes, sampled-mode launches too)
     'se_lds_gemm': ({'TFNAS_SE': 'gemm'}, _SE_SHAPES, True),
     'bn2_tables_in_their_own_pass': ({'TFNAS_FOLD': '0'}, 'tiny_s1_relu_res or tiny_7x7 or real_s2b2_28 or real_s4b2_14', True),
     'depthwise_weight_gradient_in_its_own_kernel': ({'TFNAS_DWWG': '0'}, 'tiny_s1_relu_res or real_s1b2_56 or real_s2b2_28 or real_s4b2_14', True),
+    'stride2_depthwise_weight_gradient_in_its_own_kernel': ({'TFNAS_DWWG2': '0'}, 'tiny_s2_relu or tiny_s2_swish_odd or wide_tile_edge or real_s3b1_28 or real_s5b1_14', True),
     'weight_gradients_on_the_callers_stream': ({'TFNAS_WGRAD_STREAM': '0'}, 'tiny_s1_relu_res or real_s4b2_14', True),
     # (default policy: Gram form where E is >= 100 MB, i.e. the 112 x 112 / 56 x 56 cells at B = 128 -- tests/test_gpu_b128.py)
     'expand_weight_gradient_gram_form_everywhere': ({'TFNAS_XG': 'all'}, 'tiny_s1_relu_res or tiny_ragged_res or tiny_s2_relu or real_s1b2_56 or real_s4b2_14 or real_s5b2_7', True),

@@ -766,7 +766,8 @@ static bool dwd_bwd_use(const TfnasCellDesc& d);
 static int launch_dw_bwd_data_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                      const float* D, const double* stats2, const double* red2, const float* E,
                                      const double* stats1, float* dEh, double* red1, float* part, hipStream_t s, float* cb1,
-                                     bool& done);
+                                     bool& done, bool fuse_wgrad = false);
+static bool dwd_bwd_fuses_wgrad(const TfnasCellDesc& d);
 static int launch_dw_fwd_direct(const TfnasCellDesc& d, const float* E, const double* stats1, float* D, double* stats2,
                                 float* part, hipStream_t s, bool& done);
 
