@@ -122,6 +122,8 @@ def family_algorithmic(fam, B, mode=None):
             elif fam == 'k_dw_bwd_data':
                 kk = 17.0
                 f, b = 2.0 * P * M * kk / (s * s), 4.0 * (2 * Po * M + 2 * P * M)
+                if launches != 1 and s == 2:
+                    f += 2.0 * Po * M * kk                               # + the depthwise weight gradient (same pass)
             elif fam == 'k_se_pool<bwd>':                      # k_bn2_pool: ONE pass over (dZ, D); k_bn2_finish is tiny
                 f, b = 8.0 * Po * M, 4.0 * (2 * Po * M)
                 if folded:                                     # k_bn2_gather: only the records of the dgrad epilogue
@@ -132,7 +134,11 @@ def family_algorithmic(fam, B, mode=None):
                 if fam == 'k_project_wgrad':
                     f, b = 2.0 * Po * M * oc, 4.0 * (Po * M + 2 * Po * oc)
                 elif fam == 'k_expand_wgrad':
-                    f, b = 2.0 * P * M * ic, 4.0 * (P * M + P * ic)     # Gram form: dEh and x, E is not read
+                    # Gram form where E is >= 100 MB (gemm_kernels.hip: expand_wgrad_xg): dEh and x, E is not read
+                    xg = 4.0 * P * M >= 100 * 2 ** 20
+                    f, b = 2.0 * P * M * ic, 4.0 * ((1 if xg else 2) * P * M + P * ic)
+                elif s == 2:
+                    f, b, kernels = 0.0, 0.0, 0                         # stride 2: from the backward pass (k_dwd_bwd<.., WG>)
                 else:
                     f, b = 2.0 * Po * M * 17.0, 4.0 * (2 * Po * M + P * M)
             else:
