@@ -1453,6 +1453,13 @@ static bool expand_wgrad_xg(const TfnasCellDesc& d) {
     return g_expand_xg == 2 || (size_t)d.N * d.H * d.W * d.M * sizeof(float) >= ((size_t)100 << 20);
 }
 
+bool expand_wgrad_gram_form(const TfnasCellDesc& d) { return expand_wgrad_xg(d); }
+int launch_expand_wgrad_fix(const TfnasCellDesc& d, const float* cb1, const double* red, size_t out_main, hipStream_t s) {
+    ProfScope _p2(TK_EXPAND_WGRAD, s);
+    hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 64)), dim3(256), 0, s, d, cb1, red, out_main);
+    return (int)hipGetLastError();
+}
+
 int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E, const float* cb1,
                         const float* x, float* part, hipStream_t s) {
     ProfScope _prof(TK_EXPAND_WGRAD, s);
@@ -1488,9 +1495,7 @@ int launch_expand_wgrad(const TfnasCellDesc& d, const float* dEh, const float* E
         double* red = reinterpret_cast<double*>((uintptr_t)(part + TFNAS_PART_FLOATS - red_floats + 3) & ~(uintptr_t)15);
         int rc = launch_reduce_rows(part, grid.x, (int)out_size, out_size, red, nullptr, s);
         if (rc) return rc;
-        ProfScope _p2(TK_EXPAND_WGRAD, s);
-        hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 64)), dim3(256), 0, s, d, cb1, red, out_main);
-        return (int)hipGetLastError();
+        return launch_expand_wgrad_fix(d, cb1, red, out_main, s);
     }
     size_t poff = 0;
     for (int g = 0; g < d.G; ++g) {
