@@ -153,8 +153,6 @@ VARIANTS = {            # name: (environment, shapes, sampled-mode launches too)
     'weight_gradients_on_the_callers_stream': ({'TFNAS_WGRAD_STREAM': '0'}, 'tiny_s1_relu_res or real_s4b2_14', True),
     # (default policy: Gram form where E is >= 100 MB, i.e. the 112 x 112 / 56 x 56 cells at B = 128 -- tests/test_gpu_b128.py)
     'expand_weight_gradient_gram_form_everywhere': ({'TFNAS_XG': 'all'}, 'tiny_s1_relu_res or tiny_ragged_res or tiny_s2_relu or real_s1b2_56 or real_s4b2_14 or real_s5b2_7', True),
-    # (TFNAS_XG=all also routes the one-candidate launches with ic <= 32 through the fused data + weight gradient, expand_dwg.hip)
-    'expand_gradients_gram_form_in_two_kernels': ({'TFNAS_XG': 'all', 'TFNAS_DWG': '0'}, 'tiny_s1_relu_res or tiny_s2_relu or real_s1b2_56', True),
     'expand_weight_gradient_per_element_from_E': ({'TFNAS_XG': '0'}, 'tiny_s1_relu_res or real_s1b2_56', True),
     # (the permuted contraction order of the recomputed E flips one ReLU-kink element of real_s1b2_56: DESIGN.md section 4)
     'efree_wherever_supported': ({'TFNAS_EFREE': 'all'}, 'tiny_s1_relu_res or real_s2b2_28 or real_s1b1_112', False),

@@ -438,14 +438,11 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     } else {
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1, dw_fused));
     }
-    // wide early cells of the w-step (dEh >= 100 MB, one candidate): data AND weight gradient from one pass over dEh (expand_dwg.hip)
-    const bool dwg = b.dx && expand_dgrad_splits(d) == 1 && expand_dwg_supported(d);
-    if (d.need_wgrad && !dwg) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
     if (b.dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
         float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
         TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
-        if (dwg) return launch_expand_dwg(d, b.dEh, b.x, cb1, gram, dout_res, b.wmix, b.dx, b.add_src, b.add_scale, part, s);
         TRY(launch_expand_dgrad(d, b.dEh, b.x, cb1, gram, dout_res, b.wmix, b.dx, b.dxp, s, b.add_src, b.add_scale));
     }
     return 0;

@@ -1453,8 +1453,7 @@ static bool expand_wgrad_xg(const TfnasCellDesc& d) {
     return g_expand_xg == 2 || (size_t)d.N * d.H * d.W * d.M * sizeof(float) >= ((size_t)100 << 20);
 }
 
-bool expand_wgrad_gram_form(const TfnasCellDesc& d) { return expand_wgrad_xg(d); }
-int launch_expand_wgrad_fix(const TfnasCellDesc& d, const float* cb1, const double* red, size_t out_main, hipStream_t s) {
+static int launch_expand_wgrad_fix(const TfnasCellDesc& d, const float* cb1, const double* red, size_t out_main, hipStream_t s) {
     ProfScope _p2(TK_EXPAND_WGRAD, s);
     hipLaunchKernelGGL(k_expand_wgrad_fix, dim3((unsigned)cdiv64(out_main, 64)), dim3(256), 0, s, d, cb1, red, out_main);
     return (int)hipGetLastError();

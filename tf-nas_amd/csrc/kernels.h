@@ -53,15 +53,7 @@ int launch_expand_dgrad(const TfnasCellDesc& d, const float* dEh, const float* x
                         const float* dout, const float* wmix, float* dx, float* dxp, hipStream_t s,
                         const float* add_src = nullptr, const float* add_scale = nullptr);
 int expand_dgrad_splits(const TfnasCellDesc& d);
-// Gram form of the expand weight gradient (k_expand_wgrad<XG>): would launch_expand_wgrad take it for this cell?
-bool expand_wgrad_gram_form(const TfnasCellDesc& d);
-// red (double): R of every group | Gx [ic][ic] | sx [ic]  ->  g_expand of every group (k_expand_wgrad_fix)
-int launch_expand_wgrad_fix(const TfnasCellDesc& d, const float* cb1, const double* red, size_t out_main, hipStream_t s);
-// expand_dwg.hip: expand data gradient AND weight gradient (Gram form) of the wide early cells from one pass over dEh
-bool expand_dwg_supported(const TfnasCellDesc& d);
-int launch_expand_dwg(const TfnasCellDesc& d, const float* dEh, const float* x, const float* cb1, const float* gram,
-                      const float* dout, const float* wmix, float* dx, const float* add_src, const float* add_scale, float* part,
-                      hipStream_t s);
+
 int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* cb1, const float* gram, const float* dout,
                           const float* wmix, float* dx, float* dxp, int nsl, hipStream_t s, const float* add_src = nullptr,
                           const float* add_scale = nullptr);
