@@ -217,3 +217,17 @@ def test_retrain_schedule_checkpoints_and_resume(tmp_path):
     assert [r['epoch'] for r in h2] == [3]
     for v in m2.state_dict().values():
         assert torch.isfinite(v.float()).all()
+
+
+def test_affine_blocks_with_the_gram_form_expand_weight_gradient():
+    """TFNAS_XG=all (read once per process, hence a child): the derived network's affine / eval-mode BatchNorm blocks and its
+    whole training step with the expand weight gradient in Gram form (k_expand_wgrad<XG>; default only where E >= 100 MB, i.e.
+    at the retrain batch of 256 images) -- the generic BN1-backward constants (mean_eff, rstd_eff, t1, t2) feed the same formula."""
+    import os, subprocess, sys
+    env = dict(os.environ, TFNAS_XG='all')
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = 'test_affine_block_matches_oracle or test_derived_network_train_step_and_eval_match_oracle'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_derived.py'), '-q', '-x', '-m', 'gpu', '-k', sel],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout, r.stdout[-500:]
