@@ -62,9 +62,11 @@ def test_sampled_mode_with_weight_grads(cfg, idx):
     hc.check_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=KINK_TAU)
 
 
-def test_soft_mode_also_gives_weight_grads_when_asked():
-    """autograd semantics: if weights require grad in soft mode, all 8 candidates get gradients."""
-    o, m, x, r, e = _inputs(CONFIGS[0])
+@pytest.mark.parametrize('cfg', [CONFIGS[0], CONFIGS[1], CONFIGS[2]], ids=lambda c: c[0])
+def test_soft_mode_also_gives_weight_grads_when_asked(cfg):
+    """autograd semantics: if weights require grad in soft mode, all 8 candidates get gradients (stride 2: both kernel-size passes
+    of the register-window backward carry their groups' depthwise weight gradients, k_dwd_bwd<.., WG>)."""
+    o, m, x, r, e = _inputs(cfg)
     hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=True)
 
 
