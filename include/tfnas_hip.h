@@ -35,11 +35,17 @@
 extern "C" {
 #endif
 
-/* 3 (round 5): tfnas_fx_supported (fused per-image route of the late cells); per-launch modes in TfnasCellDesc (gemm_mode, flags,
+/* 4 (round 6): every route switch of a launch lives in its descriptor (TfnasCellDesc.route: TFNAS_ROUTE_*); the library reads no
+ * environment variable at launch time (the TFNAS_* variables only seed the Python-side defaults, functions.HipModes.from_env).
+ * tfnas_cell_route() + TfnasCellDesc.fwd_route: a backward refuses a descriptor whose route differs from the forward's.
+ * TfnasCellDesc.wgrad_stream[3]: caller-owned streams for the three weight-gradient forks of ONE launch (the stem cell's backward
+ * runs alone on the chip: its four weight-gradient kernels spread over the queues the two finished paths left idle).
+ * tfnas_cls_ce_fwd_bwd / tfnas_cls_wgrad: classifier + cross-entropy of the weight step in two launches.
+ * 3 (round 5): tfnas_fx_supported (fused per-image route of the late cells); per-launch modes in TfnasCellDesc (gemm_mode, flags,
  * sync_fn / sync_user / sync_world: the process-wide setters only provide defaults).
  * 2 (round 4): arithmetic modes of the GEMMs (tfnas_set_gemm_mode); the per-group input / output mode of TfnasCellDesc (xg /
  * og), TfnasPathDesc.dual, tfnas_path_set_side_stream2 and tfnas_path_defer_join / tfnas_path_join were measured and removed */
-#define TFNAS_ABI_VERSION 3
+#define TFNAS_ABI_VERSION 4
 #define TFNAS_MAX_GROUPS 8
 #define TFNAS_MAX_SINK 4
 #define TFNAS_MAX_CELLS 32
@@ -100,18 +106,52 @@ typedef struct TfnasCellDesc {
                                  of THIS launch's 1x1 GEMMs, whatever the default is (two models in one process in different
                                  modes: an fp32-exact search net beside a bf16-GEMM derived net)                      [in] */
     int32_t flags;            /* TFNAS_CELL_LAZY_JOIN: tfnas_mbconv_bwd returns without joining its weight-gradient side
-                                 stream (see tfnas_set_lazy_join, which sets the default for descriptors without the bit) [in] */
+                                 stream (see tfnas_set_lazy_join, which sets the default for descriptors without the bit) [in]
+                                 (bit 4 was TFNAS_CELL_FXP, the fused per-image project dgrad of round 5: measured equal to the
+                                 default kernels over two rounds and deleted in round 6) */
     TfnasGroup g[TFNAS_MAX_GROUPS];
     /* per-launch cross-rank statistics hook (see tfnas_set_stats_sync: that one is the default for descriptors with
        sync_fn == NULL); sync_world >= 1 */
     int (*sync_fn)(void *user, double *table, uint64_t ndoubles, void *stream);
     void *sync_user;
-    int32_t sync_world, pad_sync;
+    int32_t sync_world;
+    int32_t route;            /* TFNAS_ROUTE_* bits: deviations of THIS launch from the library's measured per-launch policy
+                                 (0 = the policy).  The library reads no environment variable at launch time: every kernel
+                                 variant is selected here, per launch, so variants can be compared in one process           [in] */
+    int32_t fwd_route;        /* backward only: the value tfnas_cell_route() returned for the descriptor the FORWARD of these
+                                 buffers ran with (0 = not given: the backward trusts its own decision).  A backward whose own
+                                 route differs in a way that changes what the saved buffers mean (the fused per-image route
+                                 leaves ehat = BN1(E), not E, in the E buffer) returns TFNAS_EINVAL instead of silently
+                                 normalising twice                                                                          [in] */
+    int32_t pad_route;
+    void *wgrad_stream[3];    /* optional caller-owned streams for the weight-gradient kernels of this launch: fork 0 = project,
+                                 1 = squeeze-excite + depthwise, 2 = expand weight gradient.  NULL entries: the library-owned
+                                 side stream of the caller's stream (tfnas_mixedop_bwd) / of the path context.  Every stream
+                                 used is joined before tfnas_mixedop_bwd returns.  Per-cell entry points only                [in] */
 } TfnasCellDesc;
 #define TFNAS_GEMM_EXPLICIT 0x1000
 #define TFNAS_CELL_LAZY_JOIN 1
-#define TFNAS_CELL_FXP 4       /* backward of a cell with <= 14 x 14 output pixels: dZ and the BN2-backward tables from the fused per-image
-                                  project dgrad when tfnas_fxp_supported (csrc/fx_pd.inc) */
+/* TfnasCellDesc.route (ABI 4; rounds 2-5 read these from TFNAS_* environment variables latched once per process) */
+#define TFNAS_ROUTE_FX_OFF 0x1        /* frozen-weight launches of the 14 x 14 / 7 x 7 cells through the materialised route instead
+                                         of the fused per-image kernels (csrc/fx_kernels.hip)                                   */
+#define TFNAS_ROUTE_FOLD_OFF 0x2      /* per-image BN2-backward tables in their own pass over (dZ, D) (k_bn2_pool) instead of the
+                                         epilogue of k_project_dgrad + k_bn2_gather                                             */
+#define TFNAS_ROUTE_DWWG_OFF 0x4      /* 3x3 depthwise weight gradient of the stride-1 ring cells from its own kernel instead of
+                                         the backward-data pass                                                                 */
+#define TFNAS_ROUTE_DWWG2_OFF 0x8     /* the same for the register-window pass of the stride-2 cells                           */
+#define TFNAS_ROUTE_XG_OFF 0x10       /* expand weight gradient never in Gram form                                              */
+#define TFNAS_ROUTE_XG_ALL 0x20       /* ... in Gram form wherever the shape allows (default: where E >= 100 MB)                */
+#define TFNAS_ROUTE_DW_SHIFT 6        /* 2 bits: 0 per-launch policy, 1 register-window kernels wherever the geometry allows,   */
+#define TFNAS_ROUTE_DW_MASK 0xc0      /*         2 LDS ring / tile kernels only, 3 tile kernels only                            */
+#define TFNAS_ROUTE_SE_SHIFT 8        /* 2 bits: 0 wave-level MFMA kernels for the excite FCs, 1 one fused per-image kernel,    */
+#define TFNAS_ROUTE_SE_MASK 0x300     /*         2 LDS-tiled GEMMs                                                              */
+#define TFNAS_ROUTE_WGRAD_INLINE 0x400 /* weight-gradient kernels on the caller's stream (no side stream)                       */
+#define TFNAS_ROUTE_GRAM2 0x800       /* BN1-backward correction operator through the round-2 split-K GEMM + reduction instead
+                                         of the one-launch k_gram1 (csrc/gemm_kernels.hip)                                      */
+#define TFNAS_ROUTE_ALL 0xfff
+/* tfnas_cell_route(): TFNAS_ROUTE_TAKEN_VALID | the routes a forward of the (planned) descriptor takes */
+#define TFNAS_ROUTE_TAKEN_VALID 0x1
+#define TFNAS_ROUTE_TAKEN_FX 0x2      /* fused per-image route: the E buffer holds ehat = BN1(x W1^T) after the forward         */
 
 /* Element counts / offsets of every caller-allocated buffer of one cell. */
 typedef struct TfnasCellWs {
@@ -176,16 +216,17 @@ int tfnas_cell_ws(const TfnasCellDesc *d, TfnasCellWs *ws);
  * and BN1's batch statistics come from the ic x ic Gram matrix of x).  Currently: TFNAS_MODE_CELL, need_wgrad = 0
  * (the alpha-step: frozen weights), ic in {16, 24, 40}.  Same arithmetic contract as the E path (fp32, <= 1e-3). */
 int tfnas_efree_supported(const TfnasCellDesc *d);
+/* What a forward of the (planned) descriptor does with the saved buffers -- a pure function of the descriptor (geometry,
+ * need_wgrad, route, sync hook): TFNAS_ROUTE_TAKEN_VALID | TFNAS_ROUTE_TAKEN_*.  Callers that plan the backward with a descriptor
+ * of their own (other need_wgrad, another sync hook) store it in that descriptor's fwd_route; the backward then refuses
+ * (TFNAS_EINVAL) instead of misreading the E buffer.  The Python mirror does this for every launch (functions._cell_forward). */
+int tfnas_cell_route(const TfnasCellDesc *d);
 /* 1 when an E-free launch of the (planned) cell takes the FUSED PER-IMAGE route (csrc/fx_kernels.hip): stride 1, images of at
  * most 14 x 14 pixels, 64 <= ic <= 192 (a multiple of 16), frozen weights -- the supernet's cells at 14 x 14 and 7 x 7.  One kernel
  * per direction runs expand 1x1 + BN1 + activation + depthwise k x k (models/layers.py:542-552) for a group of whole images x a
  * slice of mid channels; neither E nor its gradient is ever written (the dEh buffer of tfnas_mixedop_bwd is used as scratch for
  * partial sums of dx).  Implies tfnas_efree_supported. */
 int tfnas_fx_supported(const TfnasCellDesc *d);
-/* 1 when the project data gradient of the (planned) cell can run as the fused per-image kernel (csrc/fx_pd.inc): at most 14 x 14
- * output pixels, 16 <= oc <= 256 (a multiple of 4).  dZ = dP W_proj and the per-image BN2-backward tables in one pass, the
- * BN3-backward operand resident in registers.  A VARIANT (TFNAS_CELL_FXP / TFNAS_FXP=1): measured equal to the default kernels. */
-int tfnas_fxp_supported(const TfnasCellDesc *d);
 
 /* MixedOP forward.
  *   soft mode  (G=8, wmix = device float[8] = gumbel-softmax weights):

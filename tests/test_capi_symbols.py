@@ -36,7 +36,7 @@ def test_header_functions_are_all_exported_and_bound(lib):
 
 def test_struct_layouts(lib):
     from tfnas_amd import _lib
-    assert lib.tfnas_abi_version() == 3
+    assert lib.tfnas_abi_version() == 4
     assert lib.tfnas_sizeof(0) == C.sizeof(_lib.TfnasGroup)
     assert lib.tfnas_sizeof(1) == C.sizeof(_lib.TfnasCellDesc)
     assert lib.tfnas_sizeof(2) == C.sizeof(_lib.TfnasCellWs)
@@ -70,8 +70,8 @@ def test_plan_and_workspace_geometry(lib):
 
 
 def test_fused_route_queries_on_the_supernet_geometries(lib):
-    """tfnas_fx_supported / tfnas_fxp_supported are host-side plan logic (no launch): which of the supernet's 18 cells (batch 128,
-    all candidates, frozen weights) each fused route covers, the variant flag, and what switches them off."""
+    """tfnas_fx_supported / tfnas_cell_route are host-side plan logic (no launch): which of the supernet's 18 cells (batch 128,
+    all candidates, frozen weights) the fused per-image route covers, what switches it off, and the route word's validation."""
     from tfnas_amd import _lib
     cells = [(16, 24, 2, 112), (24, 24, 1, 56), (24, 40, 2, 56), (40, 40, 1, 28), (40, 40, 1, 28), (40, 80, 2, 28),
              (80, 80, 1, 14), (80, 80, 1, 14), (80, 80, 1, 14), (80, 112, 1, 14), (112, 112, 1, 14), (112, 112, 1, 14),
@@ -81,22 +81,63 @@ def test_fused_route_queries_on_the_supernet_geometries(lib):
         mids = (3 * ic, 6 * ic) * 4
         d = _desc(N=128, H=hw, W=hw, ic=ic, oc=oc, stride=stride, mids=mids, ks=(3, 3, 5, 5) * 2, ses=(0,) * 4 + (4 * (ic // 4),) * 4)
         assert lib.tfnas_cell_plan(C.byref(d)) == 0
-        got.append((lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_fxp_supported(C.byref(d))))
+        got.append((lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_cell_route(C.byref(d))))
     fx = [int(6 <= i <= 16 and i != 13 or i == 17) for i in range(18)]          # stride 1, 14 x 14 / 7 x 7, 64 <= ic <= 192
-    fxp = [int(i >= 5 and i != 17) for i in range(18)]                           # <= 14 x 14 OUTPUT pixels, oc <= 256
-    assert [g[0] for g in got] == fx and [g[1] for g in got] == fxp
-    # trainable weights: the fused expand / depthwise routes are refused (their weight gradients need E), the project dgrad is not
+    assert [g[0] for g in got] == fx
+    assert [g[1] for g in got] == [_lib.ROUTE_TAKEN_VALID | (_lib.ROUTE_TAKEN_FX if f else 0) for f in fx]
+    # trainable weights, the route bit, a non-x3 arithmetic and a sync hook each send the launch down the materialised route
     d = _desc(N=128, H=14, W=14, ic=112, oc=112, mids=(336, 672) * 4, ks=(3, 3, 5, 5) * 2, ses=(0,) * 8)
     lib.tfnas_cell_plan(C.byref(d))
+    assert lib.tfnas_fx_supported(C.byref(d)) == 1
     d.need_wgrad = 1
-    assert (lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_fxp_supported(C.byref(d))) == (0, 1)
-    # unknown flag bits are refused by the plan, the variant bit is accepted
+    assert (lib.tfnas_fx_supported(C.byref(d)), lib.tfnas_cell_route(C.byref(d))) == (0, _lib.ROUTE_TAKEN_VALID)
+    d.need_wgrad = 0
+    d.route = _lib.ROUTE_FX_OFF
+    assert lib.tfnas_fx_supported(C.byref(d)) == 0
+    d.route = 0
+    d.gemm_mode = _lib.GEMM_EXPLICIT | _lib.GEMM_MODES['f32']
+    assert lib.tfnas_fx_supported(C.byref(d)) == 0
+    d.gemm_mode = _lib.GEMM_EXPLICIT | _lib.GEMM_MODES['x3']
+    assert lib.tfnas_fx_supported(C.byref(d)) == 1
+    # unknown flag / route bits are refused by the plan, every defined route bit is accepted
     d = _desc()
-    d.flags = _lib.CELL_FXP | _lib.CELL_LAZY_JOIN
+    d.flags = _lib.CELL_LAZY_JOIN
+    d.route = (_lib.ROUTE_FX_OFF | _lib.ROUTE_FOLD_OFF | _lib.ROUTE_DWWG_OFF | _lib.ROUTE_DWWG2_OFF | _lib.ROUTE_XG_ALL
+               | _lib.ROUTE_DW['tiled'] | _lib.ROUTE_SE['gemm'] | _lib.ROUTE_WGRAD_INLINE | _lib.ROUTE_GRAM2)
     assert lib.tfnas_cell_plan(C.byref(d)) == 0
-    for bad in (2, 8):
+    for bad in (2, 4, 8):
         d.flags = bad
         assert lib.tfnas_cell_plan(C.byref(d)) == -1
+    d.flags = 0
+    for bad in (0x1000, _lib.ROUTE_XG_OFF | _lib.ROUTE_XG_ALL, 3 << 8, 1 << 20):
+        d.route = bad
+        assert lib.tfnas_cell_plan(C.byref(d)) == -1
+    d.route = 0
+    d.fwd_route = 4
+    assert lib.tfnas_cell_plan(C.byref(d)) == -1
+
+
+def test_library_reads_no_environment_variable():
+    """ABI 4: every route switch is in the descriptor; the TFNAS_* variables only seed the Python mirror's default route word."""
+    import os
+    import subprocess
+    from tfnas_amd import _lib
+    from tfnas_amd import functions as F
+    out = subprocess.run(['strings', _lib.LIB_PATH], capture_output=True, text=True).stdout.split()
+    hits = [w for w in out if w.startswith('TFNAS_') and w not in ('TFNAS_ABLATE_MASK',)]
+    assert not hits, hits
+    assert F.route_from_env({}) == 0
+    assert F.route_from_env({'TFNAS_FX': '0', 'TFNAS_DW': 'lds', 'TFNAS_SE': 'fused', 'TFNAS_XG': 'all'}) == (
+        _lib.ROUTE_FX_OFF | _lib.ROUTE_DW['lds'] | _lib.ROUTE_SE['fused'] | _lib.ROUTE_XG_ALL)
+    assert F.route_bits(fold=False, dwwg=False, dwwg2=False, xg='0', wgrad_stream=False, gram=2) == (
+        _lib.ROUTE_FOLD_OFF | _lib.ROUTE_DWWG_OFF | _lib.ROUTE_DWWG2_OFF | _lib.ROUTE_XG_OFF | _lib.ROUTE_WGRAD_INLINE | _lib.ROUTE_GRAM2)
+    m = F.HipModes(route=F.route_bits(dw='tiled'))
+    d = _lib.TfnasCellDesc()
+    m.apply(d)
+    assert d.route == _lib.ROUTE_DW['tiled']
+    import copy
+    m.sync = (1, 2, 2)
+    assert copy.deepcopy(m).sync is None and copy.deepcopy(m).route == m.route          # a copied model never inherits the hook
 
 
 def test_error_codes(lib):

@@ -69,6 +69,27 @@ def test_cell_soft_mode_at_batch_128(ci):
     print('B=128 cell %d soft: %s' % (ci, {k: v for k, v in res.items() if k.startswith(('relu_', 'kink_', 'fp64_'))}))
 
 
+def test_late_cell_soft_mode_materialised_route_at_batch_128():
+    """The fallback of the default: cell 11 (112 -> 112, 14 x 14) with TFNAS_ROUTE_FX_OFF -- E and dE materialised, the row-streaming
+    depthwise kernels and the two-operand expand dgrad at the benchmarked size -- and the same route reached through a sync-stats
+    hook (fx_plan refuses while a hook is installed: tfnas_cell_route says so without a launch)."""
+    import ctypes as C
+    from tfnas_amd import _lib, functions as F
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    o, m, x, r, e = _cell_inputs(11)
+    F.adopt_modes(m, F.HipModes(route=F.route_bits(fx=False)))
+    res = hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=4e-6)
+    assert any(k.endswith('.dEh') for k in res)
+    F.adopt_modes(m, F.HipModes())
+    plan = m._plan(tuple(range(8)))
+    d, _ = plan.desc(128, 14, 14)
+    assert _lib.lib().tfnas_cell_route(C.byref(d)) == _lib.ROUTE_TAKEN_VALID | _lib.ROUTE_TAKEN_FX
+    hook = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)(lambda u, t, n, s: 0)
+    d.sync_fn, d.sync_world = C.cast(hook, C.c_void_p), 2
+    assert _lib.lib().tfnas_cell_route(C.byref(d)) == _lib.ROUTE_TAKEN_VALID          # sync-stats mode: the materialised route
+    d.sync_fn, d.sync_world = None, 0
+
+
 @pytest.mark.parametrize('ci,idx', [(0, 1), (1, 5), (2, 6), (3, 4), (5, 2), (6, 7), (9, 0), (11, 3), (13, 5), (15, 7), (17, 6)])
 def test_cell_sampled_mode_with_weight_grads_at_batch_128(ci, idx):
     torch.set_num_threads(min(32, os.cpu_count() or 8))

@@ -138,38 +138,86 @@ def test_backward_without_input_grad_only_produces_dwmix():
     assert torch.allclose(w_m.grad.cpu(), w_o.grad, atol=1e-3 + 1e-3 * float(w_o.grad.abs().max()))
 
 
-# Every execution variant a runtime switch can select is compared with the ORACLE (not only with the default route, which is
-# what tests/test_gpu_variants.py does): the switches are read once per process, hence one pytest child per variant running the
-# soft-mode and sampled-mode stage-by-stage comparisons above on the shapes that exercise the switched kernels.
-_DW_SHAPES = 'tiny_s2_swish_odd or wide_tile_edge or real_s1b2_56 or real_s3b1_28 or real_s4b2_14 or real_s5b2_7'
-_SE_SHAPES = 'tiny_ragged_res or real_s2b2_28 or real_s5b2_7'
-VARIANTS = {            # name: (environment, shapes, sampled-mode launches too)
-    'lds_depthwise_only': ({'TFNAS_DW': 'lds'}, _DW_SHAPES, True),
-    'register_window_depthwise_everywhere': ({'TFNAS_DW': 'direct'}, _DW_SHAPES, True),
-    'tiled_depthwise': ({'TFNAS_DW': 'tiled'}, _DW_SHAPES, True),
-    'se_fused_per_image': ({'TFNAS_SE': 'fused'}, _SE_SHAPES, True),
-    'se_lds_gemm': ({'TFNAS_SE': 'gemm'}, _SE_SHAPES, True),
-    'bn2_tables_in_their_own_pass': ({'TFNAS_FOLD': '0'}, 'tiny_s1_relu_res or tiny_7x7 or real_s2b2_28 or real_s4b2_14', True),
-    'depthwise_weight_gradient_in_its_own_kernel': ({'TFNAS_DWWG': '0'}, 'tiny_s1_relu_res or real_s1b2_56 or real_s2b2_28 or real_s4b2_14', True),
-    'stride2_depthwise_weight_gradient_in_its_own_kernel': ({'TFNAS_DWWG2': '0'}, 'tiny_s2_relu or tiny_s2_swish_odd or wide_tile_edge or real_s3b1_28 or real_s5b1_14', True),
-    'weight_gradients_on_the_callers_stream': ({'TFNAS_WGRAD_STREAM': '0'}, 'tiny_s1_relu_res or real_s4b2_14', True),
+# Every execution variant a route bit can select (TfnasCellDesc.route, ABI 4) is compared with the ORACLE (not only with the default
+# route, which is what tests/test_gpu_variants.py does).  The switches travel in the descriptor, so the variants run IN THIS PROCESS
+# -- HipModes(route=...) on the cell -- through the soft-mode and sampled-mode stage-by-stage comparisons above, on the shapes that
+# exercise the switched kernels.  (Rounds 2-5 latched them from the environment once per process: one pytest child per variant.)
+_DW_SHAPES = ('tiny_s2_swish_odd', 'wide_tile_edge', 'real_s1b2_56', 'real_s3b1_28', 'real_s4b2_14', 'real_s5b2_7')
+_SE_SHAPES = ('tiny_ragged_res', 'real_s2b2_28', 'real_s5b2_7')
+_LATE = ('real_s4b2_14', 'real_s5b2_7', 'real_s6b1_7', 'max_width_7', 'tiny_7x7')
+VARIANTS = {            # name: (route_bits keywords, shapes, sampled-mode launches too)
+    'lds_depthwise_only': (dict(dw='lds'), _DW_SHAPES, True),
+    'register_window_depthwise_everywhere': (dict(dw='direct'), _DW_SHAPES, True),
+    'tiled_depthwise': (dict(dw='tiled'), _DW_SHAPES, True),
+    'se_fused_per_image': (dict(se='fused'), _SE_SHAPES, True),
+    'se_lds_gemm': (dict(se='gemm'), _SE_SHAPES, True),
+    'bn2_tables_in_their_own_pass': (dict(fold=False), ('tiny_s1_relu_res', 'tiny_7x7', 'real_s2b2_28', 'real_s4b2_14'), True),
+    'depthwise_weight_gradient_in_its_own_kernel': (dict(dwwg=False), ('tiny_s1_relu_res', 'real_s1b2_56', 'real_s2b2_28', 'real_s4b2_14'), True),
+    'stride2_depthwise_weight_gradient_in_its_own_kernel': (dict(dwwg2=False), ('tiny_s2_relu', 'tiny_s2_swish_odd', 'wide_tile_edge', 'real_s3b1_28', 'real_s5b1_14'), True),
+    'weight_gradients_on_the_callers_stream': (dict(wgrad_stream=False), ('tiny_s1_relu_res', 'real_s4b2_14'), True),
     # (default policy: Gram form where E is >= 100 MB, i.e. the 112 x 112 / 56 x 56 cells at B = 128 -- tests/test_gpu_b128.py)
-    'expand_weight_gradient_gram_form_everywhere': ({'TFNAS_XG': 'all'}, 'tiny_s1_relu_res or tiny_ragged_res or tiny_s2_relu or real_s1b2_56 or real_s4b2_14 or real_s5b2_7', True),
-    'expand_weight_gradient_per_element_from_E': ({'TFNAS_XG': '0'}, 'tiny_s1_relu_res or real_s1b2_56', True),
-    # (the permuted contraction order of the recomputed E flips one ReLU-kink element of real_s1b2_56: DESIGN.md section 4)
-    'efree_wherever_supported': ({'TFNAS_EFREE': 'all'}, 'tiny_s1_relu_res or real_s2b2_28 or real_s1b1_112', False),
+    'expand_weight_gradient_gram_form_everywhere': (dict(xg='all'), ('tiny_s1_relu_res', 'tiny_ragged_res', 'tiny_s2_relu', 'real_s1b2_56', 'real_s4b2_14', 'real_s5b2_7'), True),
+    'expand_weight_gradient_per_element_from_E': (dict(xg='0'), ('tiny_s1_relu_res', 'real_s1b2_56'), True),
+    # the materialised frozen-weight route of the 14 x 14 / 7 x 7 cells: what TFNAS_ROUTE_FX_OFF, the sync-stats mode, a non-x3 GEMM
+    # arithmetic and every geometry fx_plan refuses fall back to (the fallback of the default must stay oracle-tested)
+    'materialised_late_cells': (dict(fx=False), _LATE, False),
+    # the BN1-backward correction operator through the round-2 split-K GEMM + reduction instead of the one-launch kernel
+    'gram_operator_split_k': (dict(gram=2), ('tiny_s1_relu_res', 'tiny_ragged_res', 'real_s2b2_28', 'real_s4b2_14', 'real_s5b2_7', 'max_width_7'), True),
 }
+_BY_NAME = {c[0]: c for c in CONFIGS}
+_VCASES = [(v, n) for v in sorted(VARIANTS) for n in VARIANTS[v][1]]
 
 
-@pytest.mark.parametrize('variant', sorted(VARIANTS))
-def test_variant_against_oracle(variant):
+@pytest.mark.parametrize('variant,shape', _VCASES, ids=['%s-%s' % c for c in _VCASES])
+def test_variant_against_oracle(variant, shape):
+    from tfnas_amd import functions as F
+    kw, _, sampled = VARIANTS[variant]
+    modes = F.HipModes(route=F.route_bits(**kw))
+    o, m, x, r, e = _inputs(_BY_NAME[shape])
+    F.adopt_modes(m, modes)
+    res = hc.check_cell(o, m, x, r, e, list(range(8)), need_wgrad=False, kink_tau=KINK_TAU, max_kink_fraction=0.02)
+    if variant == 'materialised_late_cells':
+        assert any(k.endswith('.dEh') for k in res), sorted(res)[:8]             # E and dE were materialised: the fused route did NOT run
+    if sampled:
+        for idx in (5, 6):
+            o, m, x, r, e = _inputs(_BY_NAME[shape])
+            F.adopt_modes(m, modes)
+            hc.check_cell(o, m, x, r, e, [idx], need_wgrad=True, kink_tau=KINK_TAU)
+
+
+def test_efree_wherever_supported_against_oracle():
+    """TFNAS_EFREE=all is a HOST policy of the Python mirror (functions.EFREE_STRIDE1, read at import): one pytest child.
+    (the permuted contraction order of the recomputed E flips one ReLU-kink element of real_s1b2_56: DESIGN.md section 4)"""
     import os, subprocess, sys
-    envv, shapes, sampled = VARIANTS[variant]
-    env = dict(os.environ, **envv)
+    env = dict(os.environ, TFNAS_EFREE='all')
     here = os.path.dirname(os.path.abspath(__file__))
-    which = 'test_soft_mode_all_stages' + (' or (test_sampled_mode_with_weight_grads and 5-)' if sampled else '')
-    sel = '(%s) and (%s)' % (which, shapes)
+    sel = 'test_soft_mode_all_stages and (tiny_s1_relu_res or real_s2b2_28 or real_s1b1_112)'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_cell.py'), '-q', '-x', '-m', 'gpu', '-k', sel],
                        env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'no tests ran' not in r.stdout, r.stdout[-500:]
+
+
+def test_backward_refuses_a_route_that_differs_from_the_forwards():
+    """the fused per-image route leaves ehat = BN1(E) in the E buffer.  A backward planned with another
+    need_wgrad (or route, or sync hook) than its forward would take the materialised route and normalise E a second time; with the
+    forward's route recorded in the descriptor (tfnas_cell_route -> fwd_route) tfnas_mixedop_bwd returns TFNAS_EINVAL instead."""
+    import ctypes as C
+    from tfnas_amd import _lib, functions as F
+    from tfnas_amd.functions import MixedOpFn
+    o, m, x, r, e = _inputs(_BY_NAME['real_s4b2_14'])
+    plan = m._plan(tuple(range(8)))
+    ps = plan.params()
+    for p in ps:
+        p.requires_grad_(False)
+    xm = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.softmax(e.cuda(), 0).requires_grad_(True)
+    y = MixedOpFn.apply(plan, xm, w, *ps)
+    assert y.grad_fn.fwd_route == _lib.ROUTE_TAKEN_VALID | _lib.ROUTE_TAKEN_FX
+    F.adopt_modes(m, F.HipModes(route=F.route_bits(fx=False)))                  # the model's route changes between forward and backward
+    with pytest.raises(RuntimeError, match='tfnas_mixedop_bwd failed with code -1'):
+        (y * r.cuda()).sum().backward()
+    F.adopt_modes(m, F.HipModes())
+    y = MixedOpFn.apply(plan, xm, w, *ps)
+    (y * r.cuda()).sum().backward()                                             # same route both ways: fine
+    torch.cuda.synchronize()

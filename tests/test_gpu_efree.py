@@ -127,43 +127,6 @@ def test_fx_stored_ehat_mode_matches_oracle_stage_by_stage(case, idxs):
     assert not hc.worst(res), hc.worst(res)
 
 
-# the fused per-image project dgrad (csrc/fx_pd.inc; TFNAS_CELL_FXP / HipModes.fxp): 14 x 14 and 7 x 7 outputs, an odd batch with two
-# images per workgroup, ReLU, a stride-2 cell (14 -> 7, oc = 192), narrow outputs (oc = 16: one MFMA k-step), ragged extents
-FXP_CASES = [
-    (3, 80, 80, 1, 'swish', 14, 14),
-    (5, 192, 192, 1, 'swish', 7, 7),
-    (3, 96, 96, 1, 'relu', 10, 12),
-    (4, 112, 192, 2, 'swish', 14, 14),
-    (2, 64, 16, 1, 'swish', 5, 9),
-    (2, 40, 112, 2, 'relu', 27, 25),
-]
-
-
-@pytest.mark.parametrize('case', FXP_CASES, ids=lambda c: 'n%d_%d-%d_s%d_%s_%dx%d' % c)
-@pytest.mark.parametrize('idxs,wgrad', [(list(range(8)), False), ([5], True), ([2], False)], ids=['soft', 'op5_wgrad', 'op2'])
-def test_fused_project_dgrad_matches_oracle_stage_by_stage(case, idxs, wgrad):
-    """dZ, the BN2-backward tables behind it (through dEh / dx) and every later stage of the backward, with the project dgrad on the
-    fused per-image kernel -- all-candidate launches with frozen weights, and sampled launches with and without weight gradients."""
-    import ctypes as C
-    from tfnas_amd import _lib, functions as F
-    N, ic, oc, stride, act, H, W = case
-    mids = [ic * 3 + v for v in (0, 5, 29, 9, 83, 1, 19, 12)]
-    o, m = hc.make_cell_pair(ic, oc, stride, act, mids, seed=5)
-    F.adopt_modes(m, F.HipModes(fxp=True))
-    plan = m._plan(tuple(idxs))
-    d, _ = plan.desc(N, H, W)
-    plan.bind(d, plan.params())
-    assert d.flags & _lib.CELL_FXP and _lib.lib().tfnas_fxp_supported(C.byref(d)) == 1
-    g = torch.Generator().manual_seed(13)
-    x = torch.randn(N, ic, H, W, generator=g) + 0.2
-    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    r = torch.randn(N, oc, Ho, Wo, generator=g)
-    e = torch.empty(8).exponential_(generator=g)
-    res = hc.check_cell(o, m, x, r, e, idxs, wgrad)
-    assert any(k.endswith('.dZ') for k in res)
-    assert not hc.worst(res), hc.worst(res)
-
-
 def test_efree_is_refused_when_unsupported():
     """E = NULL with a geometry no E-free kernel covers (ic = 80 at 28 x 28) must fail loudly, not fall back."""
     import ctypes as C

@@ -18,7 +18,8 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 // (one per caller stream and device) and overlap with the data-gradient chain of the same cell: fork events
 // after the producers of their operands, one join before tfnas_mixedop_bwd returns control to the caller's stream
 // (so from the caller's point of view everything is still ordered on `stream`).  They use the second half of `part`.
-// TFNAS_WGRAD_STREAM=0 disables the side stream (everything on the caller's stream, identical results).
+// TFNAS_ROUTE_WGRAD_INLINE in the descriptor disables the side stream (everything on the caller's stream, identical results).
+// TfnasCellDesc.wgrad_stream[k] != NULL: fork k goes to that caller-owned stream instead.
 struct SideCtx {
     int device;
     hipStream_t main, side;
@@ -27,14 +28,6 @@ struct SideCtx {
 static std::mutex g_side_mu;
 static std::vector<SideCtx*> g_side;
 
-static bool side_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("TFNAS_WGRAD_STREAM");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
 static SideCtx* side_for(hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -70,14 +63,36 @@ static int side_join(SideCtx* c, hipStream_t main) {
 struct SideJoinGuard {
     SideCtx* c = nullptr;
     hipStream_t main = nullptr;
+    hipStream_t extra[3] = {nullptr, nullptr, nullptr};     // caller-owned weight-gradient streams of this launch (wgrad_stream[])
     bool joined = false;
+    int join_extra() {
+        int rc = 0;
+        if (!c) return 0;
+        for (int k = 0; k < 3; ++k) {
+            hipStream_t x = extra[k];
+            if (!x || x == main) continue;
+            bool dup = false;
+            for (int q = 0; q < k; ++q) dup = dup || extra[q] == x;
+            if (dup) continue;
+            // (the context's fork events are free again here: every fork's wait was enqueued long ago)
+            hipError_t e = hipEventRecord(c->fork[3], x);
+            if (e == hipSuccess) e = hipStreamWaitEvent(main, c->fork[3], 0);
+            if (e != hipSuccess) {
+                (void)hipStreamSynchronize(x);
+                if (!rc) rc = (int)e;
+            }
+        }
+        return rc;
+    }
     int join() {
         joined = true;
-        return side_join(c, main);
+        const int r0 = side_join(c, main), r1 = join_extra();
+        return r0 ? r0 : r1;
     }
     ~SideJoinGuard() {
         if (!joined && c) {
             if (side_join(c, main) != 0) (void)hipStreamSynchronize(c->side);
+            (void)join_extra();
         }
     }
 };
@@ -93,13 +108,11 @@ extern "C" int tfnas_set_lazy_join(int on) {
 extern "C" int tfnas_side_stream(void* stream, void** side) {
     if (!side) return TFNAS_ENULL;
     *side = nullptr;
-    if (!side_enabled()) return 0;
     SideCtx* c = side_for(S(stream));
     if (c) *side = (void*)c->side;
     return 0;
 }
 extern "C" int tfnas_side_join(void* stream) {
-    if (!side_enabled()) return 0;
     return side_join(side_for(S(stream)), S(stream));
 }
 
@@ -145,6 +158,27 @@ extern "C" uint64_t tfnas_sizeof(int which) {
     }
 }
 
+#define TRY(call)               \
+    do {                        \
+        int _r = (call);        \
+        if (_r != 0) return _r; \
+    } while (0)
+
+// the per-launch modes of a descriptor (callers may change them between tfnas_cell_plan and a launch: every entry point re-checks)
+static int check_modes(const TfnasCellDesc* d) {
+    if (d->gemm_mode != 0) {
+        const int gm = d->gemm_mode & ~(TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_EVERYWHERE);
+        if (!(d->gemm_mode & TFNAS_GEMM_EXPLICIT) || (gm != 0 && gm != 1 && gm != 3 && gm != 6)) return TFNAS_EINVAL;
+    }
+    if (d->flags & ~TFNAS_CELL_LAZY_JOIN) return TFNAS_EINVAL;
+    if (d->route & ~TFNAS_ROUTE_ALL) return TFNAS_EINVAL;
+    if ((d->route & TFNAS_ROUTE_XG_OFF) && (d->route & TFNAS_ROUTE_XG_ALL)) return TFNAS_EINVAL;
+    if ((d->route & TFNAS_ROUTE_SE_MASK) == TFNAS_ROUTE_SE_MASK) return TFNAS_EINVAL;     // (3 is not an excite-FC variant)
+    if (d->fwd_route & ~(TFNAS_ROUTE_TAKEN_VALID | TFNAS_ROUTE_TAKEN_FX)) return TFNAS_EINVAL;
+    if (d->sync_fn && d->sync_world < 1) return TFNAS_ERANGE;
+    return 0;
+}
+
 extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (!d) return TFNAS_ENULL;
     if (d->G < 1 || d->G > TFNAS_MAX_GROUPS) return TFNAS_ERANGE;
@@ -164,12 +198,7 @@ extern "C" int tfnas_cell_plan(TfnasCellDesc* d) {
     if (d->stride != 1 && d->stride != 2) return TFNAS_EINVAL;
     if (d->act != TFNAS_ACT_RELU && d->act != TFNAS_ACT_SWISH) return TFNAS_EINVAL;
     if (d->has_res && (d->ic != d->oc || d->stride != 1)) return TFNAS_EINVAL;
-    if (d->gemm_mode != 0) {
-        const int gm = d->gemm_mode & ~(TFNAS_GEMM_EXPLICIT | TFNAS_GEMM_EVERYWHERE);
-        if (!(d->gemm_mode & TFNAS_GEMM_EXPLICIT) || (gm != 0 && gm != 1 && gm != 3 && gm != 6)) return TFNAS_EINVAL;
-    }
-    if (d->flags & ~(TFNAS_CELL_LAZY_JOIN | TFNAS_CELL_FXP)) return TFNAS_EINVAL;
-    if (d->sync_fn && d->sync_world < 1) return TFNAS_ERANGE;
+    TRY(check_modes(d));
     // conv output size with pad = k/2 (same for k = 3 and 5)
     d->Ho = (d->H - 1) / d->stride + 1;
     d->Wo = (d->W - 1) / d->stride + 1;
@@ -238,17 +267,16 @@ extern "C" int tfnas_cell_ws(const TfnasCellDesc* d, TfnasCellWs* ws) {
     return 0;
 }
 
-#define TRY(call)               \
-    do {                        \
-        int _r = (call);        \
-        if (_r != 0) return _r; \
-    } while (0)
-
 extern "C" int tfnas_efree_supported(const TfnasCellDesc* dp) { return (dp && efree_supported(*dp)) ? 1 : 0; }
-extern "C" int tfnas_fxp_supported(const TfnasCellDesc* dp) { return (dp && fxp_supported(*dp, (size_t)1 << 40)) ? 1 : 0; }
 extern "C" int tfnas_fx_supported(const TfnasCellDesc* dp) {
     return (dp && dp->mode == TFNAS_MODE_CELL && !dp->need_wgrad && !efree_ic_small(dp->ic) && fx_supported(*dp)) ? 1 : 0;
 }
+// what a forward of this descriptor leaves in the saved buffers (tfnas_hip.h): the one decision of cell_fwd_impl that changes
+// their MEANING is the fused per-image route (ehat instead of E); affine / eval BatchNorm launches (tfnas_mbconv_*) never take it
+static int route_taken(const TfnasCellDesc& d, bool affine) {
+    return TFNAS_ROUTE_TAKEN_VALID | ((!affine && fx_supported(d)) ? TFNAS_ROUTE_TAKEN_FX : 0);
+}
+extern "C" int tfnas_cell_route(const TfnasCellDesc* dp) { return dp ? route_taken(*dp, false) : 0; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // One cell, forward / backward: the launch sequences shared by the per-cell entry points below and by the path level
@@ -311,10 +339,10 @@ int cell_fwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellFwdB
 
 // make `side` wait for everything enqueued on `main` so far; returns the stream to launch on
 static hipStream_t fork_to(const CellSide* so, int k, hipStream_t main) {
-    if (!so || !so->side) return main;
-    if (hipEventRecord(so->fork[k], main) != hipSuccess || hipStreamWaitEvent(so->side, so->fork[k], 0) != hipSuccess)
+    if (!so || !so->side[k] || so->side[k] == main) return main;
+    if (hipEventRecord(so->fork[k], main) != hipSuccess || hipStreamWaitEvent(so->side[k], so->fork[k], 0) != hipSuccess)
         return main;
-    return so->side;
+    return so->side[k];
 }
 
 static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site, double* red, hipStream_t s) {
@@ -327,12 +355,8 @@ static int bn_bwd_fix(const TfnasCellDesc& d, const TfnasBnAffine* bn, int site,
     return 0;
 }
 
-// TFNAS_FOLD = 1 (default) | 0: BN2-backward tables in the epilogue of k_project_dgrad / in their own pass (k_bn2_pool); both
+// TFNAS_ROUTE_FOLD_OFF: BN2-backward tables in their own pass (k_bn2_pool) instead of the epilogue of k_project_dgrad; both
 // are compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
-static const bool g_project_fold = [] {
-    const char* e = getenv("TFNAS_FOLD");
-    return !(e && e[0] == '0');
-}();
 
 int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdBufs& b0, hipStream_t s, const CellSide* so) {
     const TfnasBnAffine* bn = b0.bn;
@@ -340,6 +364,9 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     if (bn) dc.eps = -1.f;
     const TfnasCellDesc& d = dc;
     CellBwdBufs b = b0;
+    // the forward's route, when the caller recorded it (tfnas_cell_route -> fwd_route): a backward that would read the E buffer
+    // differently from how the forward wrote it (need_wgrad or the sync hook changed in between) refuses
+    if ((d0.fwd_route & TFNAS_ROUTE_TAKEN_VALID) && route_taken(d0, bn != nullptr) != d0.fwd_route) return TFNAS_EINVAL;
     const float* dout_res = b0.dout;                       // the residual branch sees the unscaled gradient
     if (b0.drop_scale && d.has_res) {
         if (!b0.dout_s) return TFNAS_ENULL;
@@ -386,11 +413,8 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     // (policy, measured per cell at B = 128: the epilogue's column-wise D loads cost more than k_bn2_pool's streaming pass on the
     //  write-bound all-candidate launches of the 112 x 112 / 56 x 56 cells -- cell 1: 0.99 -> 1.04 ms -- and less everywhere else:
     //  cell 10 sampled 0.126 -> 0.103 ms, cell 15 all candidates 0.286 -> 0.252 ms)
-    const bool fold = fused2 && g_project_fold && project_fold_ok(d, (size_t)ws.dEh) && (d.G == 1 || d.Ho * d.Wo <= 784);
-    if (fused2 && b.D && fxp_wanted(d) && fxp_supported(d, (size_t)ws.dEh)) {
-        // late cells (<= 14 x 14 output pixels): dZ and the tables in one fused per-image kernel (fx_pd.inc)
-        TRY(launch_fx_pdgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.D, stats2, b.dZ, part, dgate, b.dEh, s));
-    } else if (fold) {
+    const bool fold = fused2 && !(d.route & TFNAS_ROUTE_FOLD_OFF) && project_fold_ok(d, (size_t)ws.dEh) && (d.G == 1 || d.Ho * d.Wo <= 784);
+    if (fold) {
         TRY(launch_project_dgrad(d, b.dout, b.Pr, stats3, red3, b.wmix, b.dZ, s, b.D, stats2, b.dEh));
         TRY(launch_bn2_gather(d, b.dEh, dgate, part, s));
     } else {
@@ -454,6 +478,7 @@ extern "C" int tfnas_mixedop_fwd(const TfnasCellDesc* dp, const float* x, const 
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
     if (!E && !efree_supported(d)) return TFNAS_ENULL;       // E may be omitted only in E-free mode (tfnas_efree_supported)
+    TRY(check_modes(dp));
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     CellFwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, part, out};
@@ -469,18 +494,22 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD) return TFNAS_EINVAL;
     if (!E && !efree_supported(d)) return TFNAS_ENULL;
+    TRY(check_modes(dp));
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
     // weight gradients: on the library's side stream (see SideCtx), scratch = second half of `part`
-    SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
+    SideCtx* sc = (d.need_wgrad && route_side(d)) ? side_for(s) : nullptr;
     SideJoinGuard guard;
     guard.c = sc;
     guard.main = s;
     CellSide so = {};
     if (sc) {
-        so.side = sc->side;
-        for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
+        for (int i = 0; i < 3; ++i) {
+            so.side[i] = d.wgrad_stream[i] ? S(d.wgrad_stream[i]) : sc->side;
+            guard.extra[i] = d.wgrad_stream[i] ? S(d.wgrad_stream[i]) : nullptr;
+            so.fork[i] = sc->fork[i];
+        }
     }
     CellBwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_ALLOC,
                      dx, dxp, dwmix, nullptr, nullptr};
@@ -494,6 +523,7 @@ extern "C" int tfnas_mbconv_fwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
     if (!dp || !bn || !x || !E || !D || !Pr || !fsmall || !stats || !part || !out) return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    TRY(check_modes(dp));
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     CellFwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, part, out};
@@ -510,17 +540,21 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    TRY(check_modes(dp));
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
     hipStream_t s = S(stream);
-    SideCtx* sc = (d.need_wgrad && side_enabled()) ? side_for(s) : nullptr;
+    SideCtx* sc = (d.need_wgrad && route_side(d)) ? side_for(s) : nullptr;
     SideJoinGuard guard;
     guard.c = sc;
     guard.main = s;
     CellSide so = {};
     if (sc) {
-        so.side = sc->side;
-        for (int i = 0; i < 3; ++i) so.fork[i] = sc->fork[i];
+        for (int i = 0; i < 3; ++i) {
+            so.side[i] = d.wgrad_stream[i] ? S(d.wgrad_stream[i]) : sc->side;
+            guard.extra[i] = d.wgrad_stream[i] ? S(d.wgrad_stream[i]) : nullptr;
+            so.fork[i] = sc->fork[i];
+        }
     }
     CellBwdBufs b = {x, nullptr, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_ALLOC,
                      dx, dxp, nullptr, nullptr, nullptr};
@@ -530,7 +564,7 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
     if (g_lazy_join || (d.flags & TFNAS_CELL_LAZY_JOIN)) {              // the caller joins later (tfnas_side_join)
         guard.joined = true;
-        return 0;
+        return guard.join_extra();               // (caller-owned streams of THIS launch are always joined here)
     }
     return guard.join();
 }

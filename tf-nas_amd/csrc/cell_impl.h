@@ -33,7 +33,7 @@ struct CellBwdBufs {
 // SE + depthwise / expand weight gradients): an event record on the data-gradient chain's stream + a stream wait on the side
 // stream each.  (A one-fork-per-cell variant was measured in round 3 -- no gain -- and removed.)
 struct CellSide {
-    hipStream_t side;
+    hipStream_t side[3];      // stream of fork k (project / SE + depthwise / expand weight gradients); nullptr: the caller's stream
     hipEvent_t fork[3];
 };
 

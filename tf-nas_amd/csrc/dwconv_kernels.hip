@@ -751,17 +751,11 @@ static int launch_dw_wgrad_tiled(const TfnasCellDesc& d, const float* dZ, const 
 static int launch_dw_wgrad_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                   const float* D, const double* stats2, const double* red2, const float* E,
                                   const double* stats1, float* part, size_t out_size, hipStream_t s, bool& done);
-// TFNAS_DW = auto (default: per launch, whichever kernel measured faster) | direct (register-window kernels wherever the geometry
-// allows) | lds (ring / tile kernels only) | tiled (tile kernels only): every choice is compared with the oracle
+// TfnasCellDesc.route, TFNAS_ROUTE_DW_*: 0 per launch, whichever kernel measured faster | 1 register-window kernels wherever the
+// geometry allows | 2 ring / tile kernels only | 3 tile kernels only: every choice is compared with the oracle
 // (tests/test_gpu_cell.py::test_variant_against_oracle)
-static int dw_variant() {
-    static const int v = [] {
-        const char* e = getenv("TFNAS_DW");
-        return !e ? 0 : !strcmp(e, "direct") ? 1 : !strcmp(e, "lds") ? 2 : !strcmp(e, "tiled") ? 3 : 0;
-    }();
-    return v;
-}
-static bool dwd_enabled();
+static inline int dw_variant(const TfnasCellDesc& d) { return route_dw(d); }
+static bool dwd_enabled(const TfnasCellDesc& d);
 static bool dwd_bwd_use(const TfnasCellDesc& d);
 static int launch_dw_bwd_data_direct(const TfnasCellDesc& d, const float* dZ, const float* gate, const float* dpooled,
                                      const float* D, const double* stats2, const double* red2, const float* E,

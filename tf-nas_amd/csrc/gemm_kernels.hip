@@ -1092,20 +1092,10 @@ static const int kNtSmall[] = {1, 2, 3, 4, 5, 7};   // N extents that are channe
     }
 // Arithmetic of the row-tiled 1x1-convolution GEMMs (gemm_x3.h): 6 = split-bf16 with six products per element pair (fp32-level
 // accuracy on the bf16 matrix pipe; the default), 0 = v_mfma_f32_16x16x4_f32, 3 = split-bf16 keeping the 2^-16 terms,
-// 1 = plain bf16.  TFNAS_GEMM = x3 | f32 | x2 | bf16 sets the process default; tfnas_set_gemm_mode overrides it.
-static int g_gemm_mode = -1;
+// 1 = plain bf16.  tfnas_set_gemm_mode sets the process default (6 until then; the Python mirror seeds it from TFNAS_GEMM).
+static int g_gemm_mode = 6;
 static int g_gemm_everywhere = 0;      // TFNAS_GEMM_EVERYWHERE: no per-launch shape policy (tests compare every mode with the oracle)
-int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("TFNAS_GEMM");
-        int m = 6;
-        if (e && !strcmp(e, "f32")) m = 0;
-        else if (e && !strcmp(e, "x2")) m = 3;
-        else if (e && !strcmp(e, "bf16")) m = 1;
-        g_gemm_mode = m;
-    }
-    return g_gemm_mode;
-}
+int gemm_mode() { return g_gemm_mode; }
 int set_gemm_mode(int m) {
     const int base = m & ~TFNAS_GEMM_EVERYWHERE;
     if (base != 0 && base != 1 && base != 3 && base != 6) return TFNAS_EINVAL;
@@ -1440,17 +1430,13 @@ int launch_expand_dgrad_x(const TfnasCellDesc& d, const float* x, const float* c
     return (int)hipGetLastError();
 }
 
-// TFNAS_XG = auto (default) | 0 | all: expand weight gradient without reading E (Gram form, k_expand_wgrad<XG>) where E is at
-// least 100 MB (measured alone at B = 128, tools/r5_xg.sh: cell 0 0.33 -> 0.24 ms, cells 1 / 2 equal; from 28 x 28 on E comes
-// from the last-level cache and the extension rows + the fix-up launch cost more than the second stream: cell 10 0.08 -> 0.11 ms)
-// / never / wherever the shape allows (tests); every choice is compared with the oracle (tests/test_gpu_cell.py)
-static const int g_expand_xg = [] {
-    const char* e = getenv("TFNAS_XG");
-    return !e ? 1 : (e[0] == '0' ? 0 : (!strcmp(e, "all") ? 2 : 1));
-}();
+// Expand weight gradient without reading E (Gram form, k_expand_wgrad<XG>) where E is at least 100 MB (measured alone at
+// B = 128, tools/r5_xg.sh: cell 0 0.33 -> 0.24 ms, cells 1 / 2 equal; from 28 x 28 on E comes from the last-level cache and the
+// extension rows + the fix-up launch cost more than the second stream: cell 10 0.08 -> 0.11 ms); TFNAS_ROUTE_XG_OFF: never,
+// TFNAS_ROUTE_XG_ALL: wherever the shape allows (tests); every choice is compared with the oracle (tests/test_gpu_cell.py)
 static bool expand_wgrad_xg(const TfnasCellDesc& d) {
-    if (!g_expand_xg || d.mode == TFNAS_MODE_STEM || (d.ic & 3) != 0) return false;
-    return g_expand_xg == 2 || (size_t)d.N * d.H * d.W * d.M * sizeof(float) >= ((size_t)100 << 20);
+    if ((d.route & TFNAS_ROUTE_XG_OFF) || d.mode == TFNAS_MODE_STEM || (d.ic & 3) != 0) return false;
+    return (d.route & TFNAS_ROUTE_XG_ALL) || (size_t)d.N * d.H * d.W * d.M * sizeof(float) >= ((size_t)100 << 20);
 }
 
 static int launch_expand_wgrad_fix(const TfnasCellDesc& d, const float* cb1, const double* red, size_t out_main, hipStream_t s) {

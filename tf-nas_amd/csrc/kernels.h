@@ -25,6 +25,11 @@ static inline uint64_t stats_world(const TfnasCellDesc& d) {
     return (y.fn && y.world > 1) ? (uint64_t)y.world : 1;
 }
 
+// route switches of a launch (TfnasCellDesc.route, tfnas_hip.h: TFNAS_ROUTE_*); 0 = the library's measured per-launch policy
+static inline int route_dw(const TfnasCellDesc& d) { return (d.route & TFNAS_ROUTE_DW_MASK) >> TFNAS_ROUTE_DW_SHIFT; }   // 0 auto, 1 direct, 2 lds, 3 tiled
+static inline int route_se(const TfnasCellDesc& d) { return (d.route & TFNAS_ROUTE_SE_MASK) >> TFNAS_ROUTE_SE_SHIFT; }   // 0 wave, 1 fused, 2 gemm
+static inline bool route_side(const TfnasCellDesc& d) { return !(d.route & TFNAS_ROUTE_WGRAD_INLINE); }
+
 // gemm_kernels.hip
 int gemm_mode();            // arithmetic of the row-tiled GEMMs (tfnas_hip.h: TFNAS_GEMM_*)
 int set_gemm_mode(int m);
@@ -75,13 +80,6 @@ int launch_fx_stats(const TfnasCellDesc& d, const float* x, double* stats1, floa
 // recomputing it; E == nullptr: nothing is stored, the backward rebuilds ehat from x
 int launch_fx_fwd(const TfnasCellDesc& d, const float* x, const double* stats1, float* E, float* D, double* stats2,
                   float* part, hipStream_t s);
-// fused per-image project dgrad (fx_pd.inc): dZ + the per-image BN2-backward tables pp / dgate (what k_bn2_pool writes) in one pass,
-// for cells with at most 14 x 14 output pixels and oc <= 256; scratch (blobs): scratch_floats floats
-bool fxp_supported(const TfnasCellDesc& d, size_t scratch_floats);
-bool fxp_wanted(const TfnasCellDesc& d);      // TFNAS_CELL_FXP on the descriptor, or TFNAS_FXP=1
-int launch_fx_pdgrad(const TfnasCellDesc& d, const float* dout, const float* Pr, const double* stats3, const double* red3,
-                     const float* wmix, const float* D, const double* stats2, float* dZ, float* pp, float* dgate, float* scratch,
-                     hipStream_t s);
 // backward: the partial sums of dE (rstd . W1) into scratch[0 .. nsl * P * ic) (nsl returned), the BN1-backward sums into
 // red1 and the cb1 table; the caller finishes with launch_expand_gram + launch_expand_dgrad_x(scratch, nsl)
 int launch_fx_bwd(const TfnasCellDesc& d, const float* x, const float* Eh, const double* stats1, const double* stats2,

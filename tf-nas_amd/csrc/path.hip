@@ -59,15 +59,6 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
         if (_r != 0) return _r; \
     } while (0)
 
-bool wgrad_side_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("TFNAS_WGRAD_STREAM");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
-
 int plan_path(PathCtx& c, const TfnasPathDesc& in, TfnasPathWs* out) {
     if (in.ncell < 1 || in.ncell > TFNAS_MAX_CELLS || in.nstage < 1 || in.nstage > TFNAS_MAX_STAGES) return TFNAS_ERANGE;
     c.planned = false;
@@ -426,11 +417,13 @@ int bwd_cell(BwdRun& r, int i) {
     CellSide so = {};
     const bool side = r.side_on && pd.cell[i].need_wgrad;
     if (side) {
-        so.side = c.side;
-        for (int k = 0; k < 3; ++k) so.fork[k] = c.fork[i][k];
+        for (int k = 0; k < 3; ++k) {
+            so.side[k] = c.side;
+            so.fork[k] = c.fork[i][k];
+        }
     }
     TRY(cell_bwd_impl(pd.cell[i], c.cws[i], b, r.s, side ? &so : nullptr));
-    if (side) HIP_TRY(hipEventRecord(c.wdone[i], so.side));
+    if (side) HIP_TRY(hipEventRecord(c.wdone[i], c.side));
     return 0;
 }
 
@@ -465,9 +458,12 @@ extern "C" int tfnas_paths_bwd(int npath, void* const* ctx, const float* const* 
         r.dwmix = dwmix ? dwmix[p] : nullptr;
         r.dcell_lat = dcell_lat ? dcell_lat[p] : nullptr;
         r.s = S(streams[p]);
-        bool any_w = false;
-        for (int i = 0; i < c->pd.ncell; ++i) any_w = any_w || c->pd.cell[i].need_wgrad;
-        r.side_on = wgrad_side_enabled() && any_w;
+        bool any_w = false, inl = false;
+        for (int i = 0; i < c->pd.ncell; ++i) {
+            any_w = any_w || c->pd.cell[i].need_wgrad;
+            inl = inl || !route_side(c->pd.cell[i]);          // (TFNAS_ROUTE_WGRAD_INLINE on any cell: the whole path runs without a side stream)
+        }
+        r.side_on = !inl && any_w;
         if (r.side_on) TRY(ensure_side(c));
     }
     const PathCtx* c0 = run[0].c;

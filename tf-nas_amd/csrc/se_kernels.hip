@@ -586,17 +586,11 @@ __global__ __launch_bounds__(256) void k_se_nn(TfnasCellDesc d, SeArgs a) {
 }
 
 // the wave-level kernels need aligned float4 rows of W_r / the gradients: every SE group's mid width a multiple of 4
-// TFNAS_SE = wave (default: wave-level MFMA kernels where the shapes allow) | fused (per-image kernels) | gemm (LDS-tiled GEMMs):
+// TfnasCellDesc.route, TFNAS_ROUTE_SE_*: 0 wave-level MFMA kernels where the shapes allow | 1 per-image kernels | 2 LDS-tiled GEMMs:
 // the three formulations of the excite FCs, every one compared with the oracle (tests/test_gpu_cell.py::test_variant_against_oracle)
-static int se_variant() {
-    static const int v = [] {
-        const char* e = getenv("TFNAS_SE");
-        return !e ? 0 : !strcmp(e, "fused") ? 1 : !strcmp(e, "gemm") ? 2 : 0;
-    }();
-    return v;
-}
+static inline int se_variant(const TfnasCellDesc& d) { return route_se(d); }
 static bool se_wave_ok(const TfnasCellDesc& d) {
-    if (se_variant() != 0) return false;
+    if (se_variant(d) != 0) return false;
     for (int g = 0; g < d.G; ++g)
         if (d.g[g].se > 0 && ((d.g[g].mc & 3) || (d.g[g].se & 3) || d.g[g].mc < 4)) return false;
     return true;
@@ -635,8 +629,8 @@ static int se_ksplit(const TfnasCellDesc& d, int mcp_max, size_t cap) {
 static size_t se_fused_lds(int mcp_max, int se_max) {
     return (size_t)(((mcp_max + 3) & ~3) + ((se_max + 3) & ~3) + 256 + SE_CH * (se_max | 1)) * sizeof(float);
 }
-static bool se_fused_ok(int mcp_max, int se_max) {
-    if (se_variant() == 2) return false;
+static bool se_fused_ok(const TfnasCellDesc& d, int mcp_max, int se_max) {
+    if (se_variant(d) == 2) return false;
     return se_max <= 256 && se_fused_lds(mcp_max, se_max) <= 60 * 1024;
 }
 
@@ -671,7 +665,7 @@ int launch_se_fc_fwd(const TfnasCellDesc& d, const float* pooled, float* hpre, f
         SEW_LAUNCH(k_se_nt, 1, dim3(cdiv(d.N, 16), cdiv(mcp_max, 64), ng))
         return (int)hipGetLastError();
     }
-    if (se_fused_ok(mcp_max, se_max)) {
+    if (se_fused_ok(d, mcp_max, se_max)) {
         const size_t shm = se_fused_lds(mcp_max, se_max);
         if (d.act == TFNAS_ACT_RELU)
             hipLaunchKernelGGL((k_se_fused_fwd<TFNAS_ACT_RELU>), dim3(d.N, ng), dim3(256), shm, s, d, pooled, hpre, gate);
@@ -701,7 +695,7 @@ int launch_se_fc_bwd(const TfnasCellDesc& d, const float* dgate, const float* ga
         SEW_LAUNCH(k_se_nn, 3, dim3(cdiv(d.N, 16), cdiv(mcp_max, 256), ng))
         return (int)hipGetLastError();
     }
-    if (se_fused_ok(mcp_max, se_max)) {
+    if (se_fused_ok(d, mcp_max, se_max)) {
         const size_t shm = se_fused_lds(mcp_max, se_max);
         if (d.act == TFNAS_ACT_RELU)
             hipLaunchKernelGGL((k_se_fused_bwd<TFNAS_ACT_RELU>), dim3(d.N, ng), dim3(256), shm, s, d, dgate, gate, hpre,

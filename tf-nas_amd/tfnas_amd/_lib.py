@@ -22,7 +22,13 @@ _W_FIELDS = ('w_expand', 'w_dw', 'w_proj', 'w_se_r', 'b_se_r', 'w_se_e', 'b_se_e
 _G_FIELDS = ('g_expand', 'g_dw', 'g_proj', 'g_se_r', 'gb_se_r', 'g_se_e', 'gb_se_e')
 
 
-GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN, CELL_FXP = 0x1000, 0x100, 1, 4
+GEMM_EXPLICIT, GEMM_EVERYWHERE, CELL_LAZY_JOIN = 0x1000, 0x100, 1
+# TfnasCellDesc.route (include/tfnas_hip.h: TFNAS_ROUTE_*) -- every kernel-variant switch of a launch; 0 = the library's policy
+ROUTE_FX_OFF, ROUTE_FOLD_OFF, ROUTE_DWWG_OFF, ROUTE_DWWG2_OFF, ROUTE_XG_OFF, ROUTE_XG_ALL = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+ROUTE_DW = {'auto': 0, 'direct': 1 << 6, 'lds': 2 << 6, 'tiled': 3 << 6}
+ROUTE_SE = {'wave': 0, 'fused': 1 << 8, 'gemm': 2 << 8}
+ROUTE_WGRAD_INLINE, ROUTE_GRAM2 = 0x400, 0x800
+ROUTE_TAKEN_VALID, ROUTE_TAKEN_FX = 1, 2
 GEMM_MODES = {'f32': 0, 'bf16': 1, 'x2': 3, 'x3': 6}
 
 
@@ -36,7 +42,8 @@ class TfnasCellDesc(C.Structure):
                                           'Ho', 'Wo', 'M', 'SE')]
                 + [('eps', C.c_float), ('mode', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
                    ('stor', C.c_int32), ('gemm_mode', C.c_int32), ('flags', C.c_int32), ('g', TfnasGroup * MAX_GROUPS),
-                   ('sync_fn', C.c_void_p), ('sync_user', C.c_void_p), ('sync_world', C.c_int32), ('pad_sync', C.c_int32)])
+                   ('sync_fn', C.c_void_p), ('sync_user', C.c_void_p), ('sync_world', C.c_int32), ('route', C.c_int32),
+                   ('fwd_route', C.c_int32), ('pad_route', C.c_int32), ('wgrad_stream', C.c_void_p * 3)])
 
 
 class TfnasCellWs(C.Structure):
@@ -102,7 +109,7 @@ _PROTOS = {
     'tfnas_arch_bwd': (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P), _P]),
     'tfnas_efree_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_fx_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
-    'tfnas_fxp_supported': (C.c_int, [C.POINTER(TfnasCellDesc)]),
+    'tfnas_cell_route': (C.c_int, [C.POINTER(TfnasCellDesc)]),
     'tfnas_arch_project': (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     'tfnas_arch_sample': (C.c_int, [C.c_int, C.POINTER(_P), _P, _P, C.c_float, C.c_int, _P, _P]),
     'tfnas_sink_fwd': (C.c_int, [C.c_int, _P, C.POINTER(_P), _P, C.c_uint64, _P, _P, _P, _P]),
@@ -136,11 +143,18 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)        # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if l.tfnas_abi_version() != 3:
+        if l.tfnas_abi_version() != 4:
             raise RuntimeError('tfnas_amd: ABI version mismatch')
         for which, st in enumerate((TfnasGroup, TfnasCellDesc, TfnasCellWs, TfnasStage, TfnasPathDesc, TfnasPathWs, TfnasBnAffine)):
             if l.tfnas_sizeof(which) != C.sizeof(st):
                 raise RuntimeError('tfnas_amd: struct layout mismatch for %s' % st.__name__)
+        # the library reads no environment variable (ABI 4): TFNAS_GEMM only seeds its process-wide default here
+        g = os.environ.get('TFNAS_GEMM')
+        if g is not None:
+            if g not in GEMM_MODES:
+                raise RuntimeError('tfnas_amd: TFNAS_GEMM must be one of %s' % sorted(GEMM_MODES))
+            if l.tfnas_set_gemm_mode(GEMM_MODES[g]) != 0:
+                raise RuntimeError('tfnas_amd: tfnas_set_gemm_mode failed')
         _lib_handle = l
     return l
 

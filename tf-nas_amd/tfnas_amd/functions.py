@@ -23,8 +23,36 @@ BN_EPS = 1e-5
 _EFREE_ENV = os.environ.get('TFNAS_EFREE', '1')
 EFREE = _EFREE_ENV != '0'
 EFREE_STRIDE1 = _EFREE_ENV == 'all'
-# (TFNAS_FX = 1 (default) | 0 is read by the library: frozen-weight launches of the cells at 14 x 14 / 7 x 7 through the fused
-#  per-image kernels, csrc/fx_kernels.hip / through the materialised route)
+
+
+def route_from_env(env=None):
+    """TfnasCellDesc.route bits (include/tfnas_hip.h: TFNAS_ROUTE_*) from the TFNAS_* environment variables of rounds 2-5.  Since
+    ABI 4 the library itself reads no environment: these variables only seed the DEFAULT route of the Python mirror
+    (``HipModes(route=None)``); a model / a test selects a variant per launch with ``HipModes(route=...)``.
+      TFNAS_FX=0  TFNAS_FOLD=0  TFNAS_DWWG=0  TFNAS_DWWG2=0  TFNAS_XG=0|all  TFNAS_DW=direct|lds|tiled  TFNAS_SE=fused|gemm
+      TFNAS_WGRAD_STREAM=0  TFNAS_GRAM=2"""
+    env = os.environ if env is None else env
+    r = 0
+    for var, bit in (('TFNAS_FX', _lib.ROUTE_FX_OFF), ('TFNAS_FOLD', _lib.ROUTE_FOLD_OFF), ('TFNAS_DWWG', _lib.ROUTE_DWWG_OFF),
+                     ('TFNAS_DWWG2', _lib.ROUTE_DWWG2_OFF), ('TFNAS_WGRAD_STREAM', _lib.ROUTE_WGRAD_INLINE)):
+        if env.get(var, '1')[:1] == '0':
+            r |= bit
+    xg = env.get('TFNAS_XG', 'auto')
+    r |= _lib.ROUTE_XG_OFF if xg[:1] == '0' else (_lib.ROUTE_XG_ALL if xg == 'all' else 0)
+    r |= _lib.ROUTE_DW.get(env.get('TFNAS_DW', 'auto'), 0) | _lib.ROUTE_SE.get(env.get('TFNAS_SE', 'wave'), 0)
+    if env.get('TFNAS_GRAM', '1') == '2':
+        r |= _lib.ROUTE_GRAM2
+    return r
+
+
+def route_bits(fx=True, fold=True, dwwg=True, dwwg2=True, xg='auto', dw='auto', se='wave', wgrad_stream=True, gram=1):
+    """Readable constructor of a route word: ``HipModes(route=route_bits(dw='tiled', fold=False))``."""
+    return route_from_env({'TFNAS_FX': '1' if fx else '0', 'TFNAS_FOLD': '1' if fold else '0', 'TFNAS_DWWG': '1' if dwwg else '0',
+                           'TFNAS_DWWG2': '1' if dwwg2 else '0', 'TFNAS_XG': xg, 'TFNAS_DW': dw, 'TFNAS_SE': se,
+                           'TFNAS_WGRAD_STREAM': '1' if wgrad_stream else '0', 'TFNAS_GRAM': str(gram)})
+
+
+ENV_ROUTE = route_from_env()
 
 
 def _stream(dev):
@@ -85,16 +113,28 @@ class HipModes:
       lazy_join    tfnas_mbconv_bwd leaves its weight-gradient kernels on the side stream (RetrainState joins once per step)
       direct_grads the derived network's blocks write weight gradients straight into the .grad views (host-side only)
       sync         None | (function pointer, user pointer, world): cross-rank BatchNorm statistics hook of this model
-      fxp          backwards of the late cells take the fused per-image project dgrad (a tested variant, equal: TFNAS_CELL_FXP)"""
+      route        None (the process default seeded from the TFNAS_* variables: ENV_ROUTE) | TFNAS_ROUTE_* bits (route_bits()):
+                   which kernel variant each launch of this model takes -- the library reads no environment variable"""
 
-    def __init__(self, gemm=None, everywhere=False, lazy_join=False, direct_grads=False, sync=None, fxp=False):
+    def __init__(self, gemm=None, everywhere=False, lazy_join=False, direct_grads=False, sync=None, route=None):
         self.gemm, self.everywhere, self.lazy_join, self.direct_grads, self.sync = gemm, everywhere, lazy_join, direct_grads, sync
-        self.fxp = fxp
+        self.route = route
+
+    # the sync hook is a raw function pointer of THIS process and THIS rank's communicator: a deep copy (an EMA / evaluation copy
+    # of the model) or a pickled model must not inherit it (it would all-reduce on one rank, or call a dangling pointer)
+    def __deepcopy__(self, memo):
+        return HipModes(self.gemm, self.everywhere, self.lazy_join, self.direct_grads, None, self.route)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['sync'] = None
+        return st
 
     def apply(self, d):
         d.gemm_mode = 0 if self.gemm is None else (_lib.GEMM_EXPLICIT | _lib.GEMM_MODES[self.gemm]
                                                    | (_lib.GEMM_EVERYWHERE if self.everywhere else 0))
-        d.flags = (_lib.CELL_LAZY_JOIN if self.lazy_join else 0) | (_lib.CELL_FXP if self.fxp else 0)
+        d.flags = _lib.CELL_LAZY_JOIN if self.lazy_join else 0
+        d.route = ENV_ROUTE if self.route is None else int(self.route)
         if self.sync is None:
             d.sync_fn, d.sync_user, d.sync_world = None, None, 0
         else:
@@ -156,6 +196,7 @@ class CellPlan:
             d.act, d.has_res, d.G, d.need_wgrad, d.eps = _lib.ACT[self.act], self.has_res, len(self.blocks), 0, BN_EPS
             for g, b in enumerate(self.blocks):
                 d.g[g].mc, d.g[g].k, d.g[g].se = b.mid_channels, b.kernel_size, b.se_channels
+            self.modes.apply(d)                        # (before the plan: it validates the modes; every launch re-checks them)
             check(_lib.lib().tfnas_cell_plan(C.byref(d)), 'tfnas_cell_plan')
             ws = TfnasCellWs()
             check(_lib.lib().tfnas_cell_ws(C.byref(d), C.byref(ws)), 'tfnas_cell_ws')
@@ -189,6 +230,9 @@ def _cell_forward(ctx, plan, xh, N, H, W, wmix, params):
     # the forward must know whether the backward will want weight gradients: the library picks its route per launch (the fused
     # per-image kernels of the late cells run with frozen weights only and leave ehat, not E, in the E buffer)
     d.need_wgrad = int(any(ctx.needs_input_grad[3:]))
+    # ... and the backward is told which route this forward took (tfnas_cell_route -> TfnasCellDesc.fwd_route): should need_wgrad,
+    # the sync hook or the route bits differ by then, tfnas_mixedop_bwd refuses instead of normalising the E buffer twice
+    ctx.fwd_route = int(_lib.lib().tfnas_cell_route(C.byref(d)))
     dev = xh.device
     _same_device(dev, list(params) + [wmix], 'a MixedOP weight / mix weight')
     # E-free mode (include/tfnas_hip.h: tfnas_efree_supported): with frozen weights (the alpha-step) the narrow early
@@ -238,11 +282,20 @@ def _cell_backward(ctx, dout, want_dx):
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
     _same_device(dev, [douth], 'the output gradient')
-    with _on(dev):
-        check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
-                                           ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
-                                           ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream(dev)), 'tfnas_mixedop_bwd')
-    d.need_wgrad = 0
+    d.fwd_route = getattr(ctx, 'fwd_route', 0)
+    ws_streams = getattr(plan, 'wgrad_streams', None)          # (stem cell of the weight step: search.SearchState hands in idle queues)
+    for k in range(3):
+        d.wgrad_stream[k] = ws_streams[k].cuda_stream if (ws_streams and ws_streams[k] is not None) else None
+    try:
+        with _on(dev):
+            check(_lib.lib().tfnas_mixedop_bwd(C.byref(d), ptr(xh), ptr(wmix), ptr(E), ptr(D), ptr(Pr), ptr(fsmall),
+                                               ptr(stats), ptr(douth), ptr(dZ), ptr(dEh), ptr(bsmall), ptr(red),
+                                               ptr(part), ptr(dx), ptr(dxp), ptr(dwmix), _stream(dev)), 'tfnas_mixedop_bwd')
+    finally:
+        d.need_wgrad = 0
+        d.fwd_route = 0
+        for k in range(3):
+            d.wgrad_stream[k] = None
     if MixedOpFn.debug_sink is not None:
         MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
     out = [None, None if dx is None else dx.permute(0, 3, 1, 2), dwmix]

@@ -268,14 +268,27 @@ class RetrainState:
         for p in a.params:
             if p.grad is None or p.grad.data_ptr() != a.grad_ptr(p):
                 p.grad = a.grad_view(p)
-        functions.retrain_context(DIRECT_GRADS, LAZY_JOIN, self.model)
+        functions.retrain_context(DIRECT_GRADS, LAZY_JOIN, self._modes_owner())
+
+    def _modes_owner(self):
+        """The module whose ``hip_modes`` the blocks of this model consult: the model itself, or -- when ``self.model`` is a
+        wrapper without one (nn.DataParallel / DDP / nn.Sequential / a user wrapper) -- the first sub-module that has it."""
+        m = self.model
+        if getattr(m, 'hip_modes', None) is not None:
+            return m
+        for sub in m.modules():
+            if getattr(sub, 'hip_modes', None) is not None:
+                return sub
+        return None                                      # (no HIP module inside: functions.retrain_context falls back to DEFAULT_MODES)
 
     def end(self):
         """Join the weight-gradient stream and leave the training-step context (also on an error path)."""
         from . import functions
-        if self.model.hip_modes.lazy_join:
+        owner = self._modes_owner()
+        modes = owner.hip_modes if owner is not None else functions.DEFAULT_MODES
+        if modes.lazy_join:
             functions.retrain_join(self.arena.device)
-        functions.retrain_context(False, False, self.model)
+        functions.retrain_context(False, False, owner)
 
     def step(self, opt, grad_clip, group=None):
         import ctypes as C

@@ -130,8 +130,14 @@ class PathRunner:
                 c += 1
         self._lat_index = torch.tensor(idx, dtype=torch.long, device=self.device)
 
-    def close(self):
+    def close(self, streams=()):
+        """Destroy the C contexts (tfnas_path_destroy waits for the context's side stream) and drop the arenas.  ``streams``: torch
+        streams that may still run kernels on the arenas -- the caching allocator then defers their reuse (record_stream) instead
+        of the caller synchronising the device."""
         for s in self._slots.values():
+            if s.arena is not None and s.arena.is_cuda:
+                for st in streams:
+                    s.arena.record_stream(st)
             self.lib.tfnas_path_destroy(s.ctx)
             s.ctx = None                            # a backward that still holds this slot must raise (_check_gen), not pass
             s.gen += 1                              # a freed context to tfnas_paths_bwd

@@ -107,17 +107,31 @@ class SearchState:
         return self._model_strong if self._model_weak is None else self._model_weak()
 
     def __del__(self):
+        # Garbage collection can run at any point of a training loop and at interpreter shutdown: no device-wide synchronisation
+        # and no CUDA calls while the interpreter is finalizing (the process teardown frees everything); a failure is reported,
+        # not swallowed
+        import sys
+        if sys.is_finalizing():
+            return
         try:
-            self.release()
-        except Exception:
-            pass
+            self.release(collected=True)
+        except Exception as e:
+            import warnings
+            warnings.warn('tfnas_amd: releasing a SearchState during garbage collection failed (%r); its path contexts leak' % (e,))
 
-    def release(self):
-        """Drop the path contexts / arenas and the back-reference the model holds (breaks the model <-> state cycle)."""
+    def release(self, collected=False):
+        """Drop the path contexts / arenas and the back-reference the model holds (breaks the model <-> state cycle).
+        Explicit call: waits for the device (kernels of the side streams may still use the arenas).  From the garbage collector
+        (``collected``): stream-scoped instead -- the arenas are handed back to the caching allocator with ``record_stream`` on
+        every stream this state launched on, and tfnas_path_destroy waits for the context's own side stream only."""
         if self.runner is not None:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()            # (kernels of the side streams may still use the arenas)
-            self.runner.close()
+            if collected:
+                streams = [s for s in [self._side_stream, self._comm_stream] + list(self._wgrad_streams) if s is not None]
+                self.runner.close(streams)
+            else:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()            # (kernels of the side streams may still use the arenas)
+                self.runner.close()
         self.runner = None
         m = self.model
         if m is not None and m.__dict__.get('_pstate') is self:

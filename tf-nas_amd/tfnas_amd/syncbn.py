@@ -70,7 +70,11 @@ def enable(group=None, model=None):
     cb = _FN(hook)
     if model is not None:
         model.hip_modes.sync = (C.cast(cb, C.c_void_p).value, None, int(world))
-        _STATE.setdefault('model_cbs', []).append(cb)  # (keeps the ctypes thunk alive)
+        # (the thunk is kept alive here; the model is tracked weakly so that disable() can clear ITS hook and enabled() /
+        #  check_equal_batch() account for per-model hooks too.  HipModes drops `sync` on deepcopy / pickling: an EMA or evaluation
+        #  copy of the model never inherits a rank's all-reduce.)
+        import weakref
+        _STATE.setdefault('model_cbs', []).append((cb, weakref.ref(model)))
         _STATE.update(group=group, world=world)
         return True
     for l in _libs():
@@ -96,14 +100,39 @@ def check_equal_batch(n, device=None):
         raise RuntimeError('tfnas_amd.syncbn: ranks run different batch sizes (%d .. %d); sync-stats needs equal shards' % (lo, hi))
 
 
-def disable():
+def disable(model=None):
+    """Remove the hook of ``model`` (its descriptors stop carrying it), or -- without an argument -- the process default AND every
+    per-model hook installed through enable(model=...)."""
+    keep = []
+    for cb, ref in _STATE.get('model_cbs', []):
+        m = ref()
+        if m is None:
+            continue
+        if model is None or m is model:
+            modes = getattr(m, 'hip_modes', None)
+            if modes is not None:
+                modes.sync = None
+        else:
+            keep.append((cb, ref))
+    _STATE['model_cbs'] = keep
+    if model is not None:
+        if not enabled():
+            _STATE.update(group=None, world=1)
+        return
     for l in _libs():
         l.tfnas_set_stats_sync(None, None, 1)
     _STATE.update(cb=None, group=None, world=1)
 
 
 def enabled():
-    return _STATE['cb'] is not None
+    """True while the process-default hook or any live model's own hook is installed."""
+    if _STATE['cb'] is not None:
+        return True
+    for _cb, ref in _STATE.get('model_cbs', []):
+        m = ref()
+        if m is not None and getattr(getattr(m, 'hip_modes', None), 'sync', None) is not None:
+            return True
+    return False
 
 
 def calls():
