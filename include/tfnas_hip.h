@@ -126,8 +126,10 @@ typedef struct TfnasCellDesc {
     int32_t pad_route;
     void *wgrad_stream[3];    /* optional caller-owned streams for the weight-gradient kernels of this launch: fork 0 = project,
                                  1 = squeeze-excite + depthwise, 2 = expand weight gradient.  NULL entries: the library-owned
-                                 side stream of the caller's stream (tfnas_mixedop_bwd) / of the path context.  Every stream
-                                 used is joined before tfnas_mixedop_bwd returns.  Per-cell entry points only                [in] */
+                                 side stream of the caller's stream.  Every stream used is joined before tfnas_mixedop_bwd
+                                 returns.  tfnas_mixedop_bwd only; with any entry set its `part` buffer must hold FOUR pieces
+                                 of tfnas_sizeof(7) floats (chain | fork 0 | fork 1 | fork 2: concurrent forks do not share
+                                 split-K scratch) instead of two                                                            [in] */
 } TfnasCellDesc;
 #define TFNAS_GEMM_EXPLICIT 0x1000
 #define TFNAS_CELL_LAZY_JOIN 1
@@ -294,6 +296,30 @@ int tfnas_head_fwd(const TfnasCellDesc *d, const float *x, float *E, double *sta
  * red doubles [M][2] are scratch. */
 int tfnas_head_bwd(const TfnasCellDesc *d, const float *x, const float *E, const double *stats, const float *dpooled,
                    float *dEh, float *cb1, double *red, float *part, float *dx, float *dxp, void *stream);
+
+/* The head's weight gradient alone (what tfnas_head_bwd does last when need_wgrad is set): g_expand of the group from dEh / E / cb1
+ * as tfnas_head_bwd left them.  A leaf of the backward: the weight step calls tfnas_head_bwd with need_wgrad = 0 on a path's stream
+ * and this on that path's weight-gradient stream, so that the cells' backward does not queue up behind it.  part: scratch of its
+ * own (tfnas_cell_ws().part floats). */
+int tfnas_head_wgrad(const TfnasCellDesc *d, const float *x, const float *E, const float *dEh, const float *cb1, float *part,
+                     void *stream);
+
+/* ---- classifier + cross-entropy tail (models/model_search.py:301-303 `self.classifier(x)`; train_search.py:107 nn.CrossEntropyLoss
+ * as called at :333, :376-379, :410, and their autograd) ---------------------------------------------------------------------------
+ * tfnas_cls_ce, one launch, everything that depends on ONE image:
+ *   logits[n][k] = bias[k] + sum_c pooled[n][c] W[k][c];  loss_n[n] = logsumexp_k logits[n] - logits[n][target[n]]
+ *   dlogits[n][k] = scale * (softmax(logits[n])[k] - [k == target[n]])   (scale = 1 / N: the mean reduction of CrossEntropyLoss)
+ *   dpooled[n][c] = sum_k dlogits[n][k] W[k][c]
+ * pooled [N][C] (C a multiple of 4), W [K][C], bias [K] or NULL, target int64 [N].
+ * tfnas_cls_wgrad, one launch, everything that sums over images -- and over the npath <= 2 bi-sampling paths of a weight step:
+ *   dW[k][c] = sum_p sum_n dlogits_p[n][k] pooled_p[n][c];  db[k] = sum_p sum_n dlogits_p[n][k];  loss = loss_scale * sum_p sum_n loss_n_p[n]
+ * (overwritten, not accumulated; loss may be NULL).  Fixed summation orders, no atomics. */
+int tfnas_cls_ce(int N, int C, int K, const float *pooled, const float *W, const float *bias, const int64_t *target, float scale,
+                 float *logits, float *loss_n, float *dlogits, float *dpooled, void *stream);
+int tfnas_cls_wgrad(int npath, int N, int C, int K, const float *const *pooled, const float *const *dlogits,
+                    const float *const *loss_n, float loss_scale, float *dW, float *db, float *loss, void *stream);
+/* dst[i] += src[i], count floats (a multiple of 4): the second path's share of a shared parameter's gradient. */
+int tfnas_add_into(float *dst, const float *src, uint64_t count, void *stream);
 
 /* Gumbel-softmax over the candidates of `ncell` cells in one launch + expected cell latency.
  *   w[c][i] = softmax_i((log_alpha[c][i] - log(e[c][i])) / T)      (F.gumbel_softmax, model_search.py:87)

@@ -79,7 +79,7 @@ def test_lazy_join_and_direct_gradients_are_per_model():
     from tfnas_amd import model_eval as me
     assert not hasattr(F, '_RETRAIN')
     src = open(me.__file__).read()
-    assert 'retrain_context(DIRECT_GRADS, LAZY_JOIN, self.model)' in src
+    assert 'retrain_context(DIRECT_GRADS, LAZY_JOIN, self._modes_owner())' in src     # (the model's own modes, also behind a wrapper)
     m = F.HipModes(lazy_join=True)
     d = __import__('tfnas_amd')._lib.TfnasCellDesc()
     m.apply(d)

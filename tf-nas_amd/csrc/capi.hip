@@ -389,6 +389,8 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     double* red1 = b.red + ws.off_red1;
     float* part = b.part;
     float* part_w = b.part_w;
+    float* part_w1 = b.part_w1 ? b.part_w1 : b.part_w;      // (forks on streams of their own must not share split-K scratch)
+    float* part_w2 = b.part_w2 ? b.part_w2 : b.part_w;
 
     if (d.need_wgrad) {
         for (int g = 0; g < d.G; ++g) {
@@ -449,7 +451,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
         if (d.SE > 0 || !dw_fused) {
             hipStream_t sw = fork_to(so, 1, s);
             if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
-            if (!dw_fused) TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w, sw));
+            if (!dw_fused) TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w1, sw));
         }
     }
     // depthwise dgrad + BN1-backward sums; the reduction of its partial rows also fills the cb1 table
@@ -462,7 +464,7 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
     } else {
         TRY(launch_dw_bwd_data(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, b.x, stats1, b.dEh, red1, part, s, cb1, dw_fused));
     }
-    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w, fork_to(so, 2, s)));
+    if (d.need_wgrad) TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w2, fork_to(so, 2, s)));
     if (b.dx && d.mode != TFNAS_MODE_STEM) {
         // dx = de W_expand (+ residual) without reading E: BN1-backward correction operator G | b in the top of `part`
         float* gram = part + TFNAS_PART_FLOATS - expand_gram_floats(d);
@@ -513,6 +515,11 @@ extern "C" int tfnas_mixedop_bwd(const TfnasCellDesc* dp, const float* x, const 
     }
     CellBwdBufs b = {x, wmix, E, D, Pr, fsmall, stats, dout, dZ, dEh, bsmall, red, part, part + TFNAS_PART_ALLOC,
                      dx, dxp, dwmix, nullptr, nullptr};
+    if (sc && (d.wgrad_stream[0] || d.wgrad_stream[1] || d.wgrad_stream[2])) {
+        // forks on different streams run concurrently: one scratch piece each (tfnas_hip.h: `part` then holds FOUR pieces)
+        b.part_w1 = part + 2 * TFNAS_PART_ALLOC;
+        b.part_w2 = part + 3 * TFNAS_PART_ALLOC;
+    }
     TRY(cell_bwd_impl(d, ws, b, s, sc ? &so : nullptr));
     return guard.join();
 }
@@ -540,6 +547,7 @@ extern "C" int tfnas_mbconv_bwd(const TfnasCellDesc* dp, const TfnasBnAffine* bn
         return TFNAS_ENULL;
     const TfnasCellDesc& d = *dp;
     if (d.mode == TFNAS_MODE_HEAD || d.G != 1) return TFNAS_EINVAL;
+    if (d.wgrad_stream[0] || d.wgrad_stream[1] || d.wgrad_stream[2]) return TFNAS_EINVAL;     // (tfnas_mixedop_bwd only)
     TRY(check_modes(dp));
     TfnasCellWs ws;
     TRY(tfnas_cell_ws(dp, &ws));
@@ -636,6 +644,15 @@ extern "C" int tfnas_head_bwd(const TfnasCellDesc* dp, const float* x, const flo
     TRY(launch_expand_dgrad(d, dEh, x, cb1, gram, nullptr, nullptr, dx, dxp, s));
     if (d.need_wgrad) TRY(launch_expand_wgrad(d, dEh, E, cb1, x, part, s));
     return 0;
+}
+
+extern "C" int tfnas_head_wgrad(const TfnasCellDesc* dp, const float* x, const float* E, const float* dEh, const float* cb1,
+                                float* part, void* stream) {
+    if (!dp || !x || !E || !dEh || !cb1 || !part) return TFNAS_ENULL;
+    const TfnasCellDesc& d = *dp;
+    if (d.mode != TFNAS_MODE_HEAD) return TFNAS_EINVAL;
+    if (!d.g[0].g_expand) return TFNAS_ENULL;
+    return launch_expand_wgrad(d, dEh, E, cb1, x, part, S(stream));
 }
 
 extern "C" int tfnas_arch_fwd(int ncell, const float* const* log_alpha, const float* e, const float* lat, float T,

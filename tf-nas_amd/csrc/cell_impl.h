@@ -21,6 +21,7 @@ struct CellBwdBufs {
     float *dZ, *dEh, *bsmall;
     double* red;
     float *part, *part_w;        // scratch of the data-gradient chain / of the weight-gradient kernels
+    float *part_w1 = nullptr, *part_w2 = nullptr;   // own scratch of forks 1 / 2 when they run on streams of their own (else part_w)
     float *dx, *dxp, *dwmix;
     const float* add_src;        // optional extra addend of dx: dx += add_scale[0] * add_src  (sink-connecting gradient,
     const float* add_scale;      //   same shape as dx; models/model_search.py:202-204 backward)

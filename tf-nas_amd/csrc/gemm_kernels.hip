@@ -919,6 +919,70 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
         }
 }
 
+// One-launch form of the same operator (round 6; the default -- TFNAS_ROUTE_GRAM2 selects the split-K GEMM + reduction above).
+// G | b is tiny (ic <= 320, K = all mid channels: 6..130 MFLOP) and sits on the data-gradient chain of EVERY cell between the
+// BN1-backward reduction and k_expand_dgrad; as a 128-row LDS-tiled GEMM split over K plus a k_reduce_rows launch it cost 13..28 us
+// + 5 us per cell (w-step trace, round 6: 40 + 40 launches, 0.9 ms of chain time per w-step).  Here a workgroup owns a 16 x 32 tile
+// of the output; its four waves take every fourth group of 4 mid channels, a lane loads its own MFMA operands straight from W
+// (A[i][k] = s_k W[k][r0 + i], B[k][j] = W[k][c0 + j]: 64-byte row pieces, W stays in L2), a batch of GB steps' loads is in flight
+// before their v_mfma_f32_16x16x4_f32; the four partial tiles are summed in double through LDS in wave order (deterministic).
+constexpr int GRAM1_GB = 6;
+__global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __restrict__ cb1, float* __restrict__ gram) {
+    __shared__ float part[4][2][16][17];
+    const int ic = d.ic;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
+    const f32x4* cb = reinterpret_cast<const f32x4*>(cb1);
+    const int r = r0 + li, ca = c0 + li, cb_ = c0 + 16 + li;
+    const bool row_w = r < ic, row_b = r == ic, oka = ca < ic, okb = cb_ < ic;
+    const int ra = row_w ? r : 0, caa = oka ? ca : 0, cbb = okb ? cb_ : 0;      // clamped addresses, values masked below
+    f32x4 acc0 = zero4(), acc1 = zero4();
+    for (int g = 0; g < d.G; ++g) {
+        const float* __restrict__ W = d.g[g].w_expand;
+        const int mc = d.g[g].mc, off = d.g[g].off;
+        const int nstep = (mc + 3) >> 2;
+        for (int s0 = wave * GRAM1_GB; s0 < nstep; s0 += 4 * GRAM1_GB) {
+            float a[GRAM1_GB], b0[GRAM1_GB], b1[GRAM1_GB];
+            f32x4 t[GRAM1_GB];
+#pragma unroll
+            for (int u = 0; u < GRAM1_GB; ++u) {
+                const int m = 4 * (s0 + u) + kq;
+                const int mm = m < mc ? m : mc - 1;
+                const float* wr = W + (size_t)mm * ic;
+                t[u] = cb[off + mm];
+                a[u] = wr[ra];
+                b0[u] = wr[caa];
+                b1[u] = wr[cbb];
+            }
+#pragma unroll
+            for (int u = 0; u < GRAM1_GB; ++u) {
+                const int m = 4 * (s0 + u) + kq;
+                const bool okm = m < mc && s0 + u < nstep;
+                const float sk = t[u].y * t[u].y * t[u].w;
+                float av = row_w ? sk * a[u] : (row_b ? sk * t[u].x - t[u].y * t[u].z : 0.f);
+                av = okm ? av : 0.f;
+                const float bv0 = (okm && oka) ? b0[u] : 0.f, bv1 = (okm && okb) ? b1[u] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv1, acc1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        part[wave][0][4 * kq + q][li] = acc0[q];
+        part[wave][1][4 * kq + q][li] = acc1[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = tid >> 4, col = tid & 15;
+        const double v = ((double)part[0][h][row][col] + (double)part[1][h][row][col]) +
+                         ((double)part[2][h][row][col] + (double)part[3][h][row][col]);
+        const int rr = r0 + row, cc = c0 + 16 * h + col;
+        if (rr <= ic && cc < ic) gram[(size_t)rr * ic + cc] = (float)v;
+    }
+}
+
 // ============================================================================ expand wgrad (TN, split-K)
 // XG = false (stem; TFNAS_XG=0):  part[split][poff_g + m*ic + c] = sum_{p in split} de[p][off_g+m] * x[p][c]  with the
 //   BN1-backward operand de = rstd (deh - t1 - ehat t2) formed per element from dEh AND E (k_reduce_rows sums the splits).
@@ -1360,6 +1424,13 @@ size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.ic + 4) * 
 int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
                        hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);
+    if (!(d.route & TFNAS_ROUTE_GRAM2)) {
+        // one launch, no K-split partials, no reduction (k_gram1); `scratch` is not used
+        for (int g = 0; g < d.G; ++g)
+            if (d.g[g].mc < 1) return TFNAS_EINVAL;
+        hipLaunchKernelGGL(k_gram1, dim3(cdiv(d.ic, 32), cdiv(d.ic + 1, 16)), dim3(256), 0, s, d, cb1, gram);
+        return (int)hipGetLastError();
+    }
     const int nt = pick_nt(d.ic, kNtSmall, 6);
     const int ng = 1;
     const size_t gsz = (size_t)(d.ic + 4) * d.ic;

@@ -92,6 +92,10 @@ _PROTOS = {
     'tfnas_head_affine_bwd': (C.c_int, [C.POINTER(TfnasCellDesc), C.POINTER(TfnasBnAffine)] + [_P] * 11),
     'tfnas_head_fwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
     'tfnas_head_bwd': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 11),
+    'tfnas_head_wgrad': (C.c_int, [C.POINTER(TfnasCellDesc)] + [_P] * 6),
+    'tfnas_cls_ce': (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    'tfnas_cls_wgrad': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _PP, _PP, _PP, C.c_float, _P, _P, _P, _P]),
+    'tfnas_add_into': (C.c_int, [_P, _P, C.c_uint64, _P]),
     'tfnas_path_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'tfnas_path_destroy': (C.c_int, [C.c_void_p]),
     'tfnas_path_set_side_stream': (C.c_int, [C.c_void_p, C.c_void_p]),

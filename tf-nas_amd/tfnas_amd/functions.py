@@ -268,7 +268,13 @@ def _cell_backward(ctx, dout, want_dx):
     d, ws = plan.desc(N, H, W)
     dev = xh.device
     need_w = any(ctx.needs_input_grad[3:])
-    grads = [torch.empty_like(p) for p in params] if need_w else None
+    # plan.grad_targets (set by search._w_step_paths around its backward): the kernels write the weight gradients straight into
+    # these tensors (the WeightArena's views) and autograd gets None for them -- no temporaries, no AccumulateGrad adds
+    direct = getattr(plan, 'grad_targets', None) if need_w else None
+    if direct is not None and (len(direct) != len(params) or any(g.shape != p.shape or g.device != p.device or not g.is_contiguous()
+                                                                 for g, p in zip(direct, params))):
+        raise RuntimeError('tfnas_amd: grad_targets do not match the parameters of this launch')
+    grads = (list(direct) if direct is not None else [torch.empty_like(p) for p in params]) if need_w else None
     plan.bind(d, params, grads)
     douth = _nhwc(dout)
     light = not want_dx and not need_w          # only d wmix is wanted: the C side returns after the BN3 sums
@@ -277,13 +283,13 @@ def _cell_backward(ctx, dout, want_dx):
     bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
     # with weight gradients the library wants twice the scratch (second half: its weight-gradient side stream)
-    part = _part(ws.part * (2 if need_w else 1), dev)
+    ws_streams = getattr(plan, 'wgrad_streams', None) if need_w else None    # (stem cell of the weight step: search.SearchState hands in idle queues)
+    part = _part(ws.part * (4 if ws_streams else (2 if need_w else 1)), dev)    # (own scratch per fork on its own stream)
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
     dwmix = torch.empty(d.G, device=dev, dtype=torch.float32) if ctx.has_w else None
     _same_device(dev, [douth], 'the output gradient')
     d.fwd_route = getattr(ctx, 'fwd_route', 0)
-    ws_streams = getattr(plan, 'wgrad_streams', None)          # (stem cell of the weight step: search.SearchState hands in idle queues)
     for k in range(3):
         d.wgrad_stream[k] = ws_streams[k].cuda_stream if (ws_streams and ws_streams[k] is not None) else None
     try:
@@ -299,7 +305,7 @@ def _cell_backward(ctx, dout, want_dx):
     if MixedOpFn.debug_sink is not None:
         MixedOpFn.debug_sink.append(dict(dZ=dZ, dEh=dEh, bsmall=bsmall, red=red, ws=ws, d=d))
     out = [None, None if dx is None else dx.permute(0, 3, 1, 2), dwmix]
-    out.extend(grads if need_w else [None] * len(params))
+    out.extend(grads if (need_w and direct is None) else [None] * len(params))
     return tuple(out)
 
 

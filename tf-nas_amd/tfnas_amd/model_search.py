@@ -272,21 +272,27 @@ class Network(nn.Module):
         def hip_params(self):
             return [self.layer.conv.weight]
 
-    def _stem(self, x):
+    def stem_plan(self):
         fs, ss = self.first_stem, self.second_stem
         if (fs.kernel_size, fs.stride, fs.in_channels, fs.act_func, ss.act_func, ss.stride) != (3, 2, 3, 'relu', 'relu', 1) \
                 or ss.inverted_bottleneck is not None or ss.squeeze_excite is None:
             raise NotImplementedError('stem geometry differs from models/model_search.py:219-220')
         if self._stem_plan is None:
             self._stem_plan = CellPlan(27, ss.out_channels, 1, 'relu', [Network._StemBlock(fs, ss)], mode=_lib.MODE_STEM, modes=self.hip_modes)
-        plan = self._stem_plan
+        return self._stem_plan
+
+    def _stem(self, x):
+        plan = self.stem_plan()
         return StemFn.apply(plan, x, None, *plan.params())
 
-    def _head(self, x):
+    def head_plan(self):
         fm = self.feature_mix_layer
         if self._head_plan is None:
             self._head_plan = CellPlan(fm.in_channels, 4, 1, fm.act_func, [Network._HeadBlock(fm)], mode=_lib.MODE_HEAD, modes=self.hip_modes)
-        return HeadFn.apply(self._head_plan, x, fm.conv.weight)
+        return self._head_plan
+
+    def _head(self, x):
+        return HeadFn.apply(self.head_plan(), x, self.feature_mix_layer.conv.weight)
 
     def stages(self):
         return [getattr(self, n) for n in self._stage_names]

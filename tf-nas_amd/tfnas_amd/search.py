@@ -55,6 +55,9 @@ class SearchState:
         self.arch = model.arch_parameters()
         self._mode = None
         self._side_stream = None
+        self._bitail = None
+        self._shared_attached = None
+        self._shared_cover = None
         self.weights_epoch = 0             # bumped by the fused optimizer steps (they write through raw pointers: no ._version)
         self._alpha_host = None            # (key, pinned [ncell, 8] copy of the log_alphas, copy-done event)
         self._step_done = []               # completion events of the most recent steps (bounds host run-ahead)
@@ -404,15 +407,36 @@ class SearchState:
             ps = self._op_params[key] = list(self.model.cells()[ci].m_ops[idx].parameters())
         return ps
 
-    def begin_weight_grads(self):
-        """Before a path-level w-step: drop last step's gradient views, zero + attach the shared parameters' arena views."""
+    def begin_weight_grads(self, overwritten=False):
+        """Before a path-level w-step: drop last step's gradient views, zero + attach the shared parameters' arena views.
+        overwritten: every shared parameter's gradient will be WRITTEN by a kernel of this step (stem cell with grad_targets,
+        fused tail): no zero-fill (three launches in front of the stem's forward)."""
         for p in self._graded:
             p.grad = None
         self._graded = []
-        for lo, n in self._shared_spans:
-            self.arena.g[lo:lo + n].zero_()
-        for p in self._shared:
-            p.grad = self.arena.grad_view(p)
+        if not overwritten:
+            for lo, n in self._shared_spans:
+                self.arena.g[lo:lo + n].zero_()
+        if self._shared_attached != self.arena.g.data_ptr() or any(p.grad is None for p in self._shared):
+            for p in self._shared:
+                p.grad = self.arena.grad_view(p)
+            self._shared_attached = self.arena.g.data_ptr()
+
+    def stem_direct(self, on):
+        """Around the backward of a path-level w-step: the stem cell writes its seven weight gradients straight into the arena
+        (plan.grad_targets) and spreads its four weight-gradient kernels over the queues the two finished paths left idle
+        (TfnasCellDesc.wgrad_stream: project -> path A's weight-gradient stream, SE + depthwise -> path B's, conv -> path B's own
+        stream).  The stem's backward runs ALONE on the chip at the end of the step; on one side stream those kernels were a
+        0.8 ms serial tail behind a 0.5 ms chain."""
+        plan = self.model.stem_plan()
+        if not on:
+            plan.grad_targets = plan.wgrad_streams = None
+            return False
+        ps = plan.params()
+        plan.grad_targets = [self.arena.grad_view(p) for p in ps]
+        if STEM_SPREAD and len(self._wgrad_streams) == 2 and self._side_stream is not None:
+            plan.wgrad_streams = [self._wgrad_streams[0], self._wgrad_streams[1], self._side_stream]
+        return True
 
     def expose_weight_grads(self, idx_lists, track=True):
         """After backward: point .grad of the sampled candidates' parameters at the arena ranges the kernels wrote.
@@ -425,6 +449,33 @@ class SearchState:
                     p.grad = self.arena.grad_view(p)
                     if track:
                         g.append(p)
+
+    def stem_direct_ok(self):
+        m = self.model
+        return hasattr(m, 'stem_plan') and all(self.arena.owns(p) for p in m.stem_plan().params())
+
+    def shared_is_stem_and_tail(self):
+        """True when every parameter outside the cells is either one of the stem cell's or the head's / classifier's (the
+        reference's Network: yes) -- then a step with the fused tail and the direct stem gradients overwrites ALL of them."""
+        if self._shared_cover is None:
+            m = self.model
+            cover = set()
+            try:
+                plan = m.stem_plan()
+                cover.update(id(p) for p in plan.params())
+                cover.add(id(m.feature_mix_layer.conv.weight))
+                cover.update(id(p) for p in m.classifier.linear.parameters())
+            except AttributeError:
+                self._shared_cover = False
+                return False
+            self._shared_cover = all(id(p) in cover for p in self._shared)
+        return self._shared_cover
+
+    def bitail(self):
+        if self._bitail is None:
+            from .tail import BiTail
+            self._bitail = BiTail(self)
+        return self._bitail
 
     def side_stream(self, device):
         """Second HIP stream for the 'random' path of the w-step (chosen once per device)."""
@@ -540,6 +591,9 @@ FUSED_OPT = os.environ.get('TFNAS_FUSED_STEP', '1') != '0'
 # data parallel: reduce the late stages' gradients while the early stages' backward is still running (SearchState.dp_begin)
 OVERLAP_ALLREDUCE = os.environ.get('TFNAS_OVERLAP_ALLREDUCE', '1') != '0'
 # choose the w-step's side streams by measured concurrency (streams.py); 0: first streams torch / the library hand out
+STEM_DIRECT = os.environ.get('TFNAS_STEM_DIRECT', '1') != '0'   # w_step: the stem cell's weight gradients straight into the arena
+STEM_SPREAD = os.environ.get('TFNAS_STEM_SPREAD', '1') != '0'   # ... and its weight-gradient kernels spread over the idle queues
+FUSED_TAIL = os.environ.get('TFNAS_FUSED_TAIL', '1') != '0'     # w_step: heads + classifier + loss of both paths through tail.py
 PICK_STREAMS = True
 INTERLEAVE_PATHS = True                 # w_step: Network.forward_bisample when the positions are known on the host
 HOST_SAMPLING = True                    # w_step: gumbel positions from the staged host copy of the log_alphas
@@ -708,7 +762,9 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
     if not fused or state._need_zero_grad:
         opt_w.zero_grad()                   # (750 parameters; the fused route never leaves a stale .grad behind)
         state._need_zero_grad = False
-    state.begin_weight_grads()
+    use_tail = bool(bi_sampling and FUSED_TAIL and fused and hasattr(model, 'head_plan'))
+    direct = bool(STEM_DIRECT and fused and state.stem_direct_ok())
+    state.begin_weight_grads(overwritten=use_tail and direct and state.shared_is_stem_and_tail())
     # The stems have no candidates: their forward is enqueued BEFORE the sampled indices are known.  After an alpha-step the
     # host has to wait for the staged copy of the new log_alphas (alpha_host below) -- i.e. for the GPU to finish that step --
     # before it can sample and plan the paths; with the stem already queued the GPU works through it (0.65 ms at B = 128)
@@ -731,7 +787,17 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
         c.last_idx = ia
     if fused:
         state.dp_begin([idx_a] if idx_b is None else [idx_a, idx_b], group)
-    if bi_sampling:
+    tail = None
+    if use_tail:
+        # both paths' heads + classifier + loss, forward AND backward, on the two paths' streams (tail.py)
+        from .tail import BiTailFn
+        cur = torch.cuda.current_stream(dev)
+        side = state.side_stream(dev)
+        oa, ob = runner.bisampled(feat, idx_a, idx_b, side)
+        tail = state.bitail()
+        wmap = runner.wgrad_streams
+        loss, logits_g = BiTailFn.apply(tail, model, oa, ob, target, side, [wmap['A'], wmap['B']] if len(wmap) == 2 else None)
+    elif bi_sampling:
         cur = torch.cuda.current_stream(dev)
         side = state.side_stream(dev)
         oa, ob = runner.bisampled(feat, idx_a, idx_b, side)
@@ -744,7 +810,15 @@ def _w_step_paths(state, x, target, opt_w, grad_clip, noise_g, host_e, rand_pos,
     else:
         logits_g = model.classifier(model._head(runner.sampled(feat, idx_a)))
         loss = F.cross_entropy(logits_g, target)
-    loss.backward()
+    if direct:
+        state.stem_direct(True)
+    try:
+        loss.backward()
+    finally:
+        if direct:
+            state.stem_direct(False)
+    if tail is not None and tail.join_stream is not None:
+        cur.wait_stream(tail.join_stream)       # (the head / classifier gradients and the loss scalar were summed on a weight-gradient stream)
     idx_lists = [idx_a] if idx_b is None else [idx_a, idx_b]
     if FUSED_OPT and state._fusable_sgd(opt_w):
         if state.expose_grads:
