@@ -91,7 +91,7 @@ def _two_states(B=4, seed=3):
         ow, oa = search.make_optimizers(m)
         out.append((m, st, ow, oa))
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, 3, 64, 64, generator=g).cuda()
+    x = torch.randn(B, 3, 224, 224, generator=g).cuda()          # (the latency table is keyed by the 224 x 224 geometry)
     y = torch.randint(0, 100, (B,), generator=g).cuda()
     return out, x, y
 
@@ -100,30 +100,38 @@ def _two_states(B=4, seed=3):
                                    dict(FUSED_TAIL=False, STEM_DIRECT=True), dict(FUSED_TAIL=True, STEM_DIRECT=True, STEM_SPREAD=False)],
                          ids=['torch_tail_autograd_stem', 'fused_tail_only', 'direct_stem_only', 'no_spread'])
 def test_weight_step_with_fused_tail_equals_the_torch_tail(flags, monkeypatch):
-    """Two w-steps + an alpha-step + a w-step from identical state: the default route (fused tail, direct + spread stem gradients)
-    against the same steps with pieces of it switched off -- same sampled paths, weights / momentum / loss within 1e-4 relative."""
+    """ONE w-step from identical state (teacher-forced: differences do not compound): the default route (fused tail, direct + spread
+    stem gradients) against the same step with pieces of it switched off -- same sampled paths; loss within 1e-5, every weight and
+    the momentum arena within 1e-4 of the tensor's largest value.  Then an alpha-step and two more w-steps on both (the routes keep
+    working after each other's steps; losses stay finite and within 1e-2 of each other)."""
     from tfnas_amd import search
     ((ma, sa, owa, oaa), (mb, sb, owb, oab)), x, y = _two_states()
     na, nb = search.NoiseSource(5), search.NoiseSource(5)
-    losses = []
-    for (m, st, ow, oa, noise, fl) in ((ma, sa, owa, oaa, na, {}), (mb, sb, owb, oab, nb, flags)):
+    runs = ((ma, sa, owa, oaa, na, {}), (mb, sb, owb, oab, nb, flags))
+
+    def setf(fl):
         for k in ('FUSED_TAIL', 'STEM_DIRECT', 'STEM_SPREAD'):
             monkeypatch.setattr(search, k, fl.get(k, True))
-        ls = []
-        for it in range(2):
-            l, _ = search.w_step(st, x, y, ow, 5.0, noise.exp(x.device), noise.rand_pos())
-            ls.append(l)
-        search.a_step(st, x, y, oa, 15.0, 0.1, 5.0, noise.exp(x.device))
-        l, lg = search.w_step(st, x, y, ow, 5.0, noise.exp(x.device), noise.rand_pos())
-        ls.append(l)
+    first = []
+    for (m, st, ow, oa, noise, fl) in runs:
+        setf(fl)
+        l, _ = search.w_step(st, x, y, ow, 5.0, noise.exp(x.device), noise.rand_pos())
         torch.cuda.synchronize()
-        losses.append([float(v) for v in ls])
-    for la, lb in zip(*losses):
-        assert abs(la - lb) <= 1e-5 + 1e-4 * abs(la), losses
+        first.append(float(l))
+    assert abs(first[0] - first[1]) <= 1e-5 * abs(first[0]) + 1e-6, first
     for (ka, pa), (kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert ka == kb
-        _close(pb.detach(), pa.detach(), ka, rtol=2e-4, atol=2e-6)
-    _close(sb.arena.m, sa.arena.m, 'momentum arena', rtol=2e-4, atol=2e-6)
+        _close(pb.detach(), pa.detach(), ka, rtol=1e-4, atol=1e-7)
+    _close(sb.arena.m, sa.arena.m, 'momentum arena', rtol=1e-4, atol=1e-7)
+    later = []
+    for (m, st, ow, oa, noise, fl) in runs:
+        setf(fl)
+        search.a_step(st, x, y, oa, 15.0, 0.1, 5.0, noise.exp(x.device))
+        ls = [search.w_step(st, x, y, ow, 5.0, noise.exp(x.device), noise.rand_pos())[0] for _ in range(2)]
+        torch.cuda.synchronize()
+        later.append([float(v) for v in ls])
+    for la, lb in zip(*later):
+        assert la == la and lb == lb and abs(la - lb) <= 1e-2 * abs(la), later
 
 
 def test_fused_tail_is_bit_deterministic_and_leaves_module_api_usable():

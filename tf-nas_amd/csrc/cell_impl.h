@@ -21,13 +21,14 @@ struct CellBwdBufs {
     float *dZ, *dEh, *bsmall;
     double* red;
     float *part, *part_w;        // scratch of the data-gradient chain / of the weight-gradient kernels
-    float *part_w1 = nullptr, *part_w2 = nullptr;   // own scratch of forks 1 / 2 when they run on streams of their own (else part_w)
     float *dx, *dxp, *dwmix;
     const float* add_src;        // optional extra addend of dx: dx += add_scale[0] * add_src  (sink-connecting gradient,
     const float* add_scale;      //   same shape as dx; models/model_search.py:202-204 backward)
     const TfnasBnAffine* bn = nullptr;
     const float* drop_scale = nullptr;
     float* dout_s = nullptr;     // scratch for drop_scale[n] * dout
+    // (appended: the launch sequences aggregate-initialise this struct positionally)
+    float *part_w1 = nullptr, *part_w2 = nullptr;   // own scratch of forks 1 / 2 when they run on streams of their own (else part_w)
 };
 
 // where the weight-gradient kernels of a cell go: `side` == nullptr -> the caller's stream.  Three forks per cell (project /

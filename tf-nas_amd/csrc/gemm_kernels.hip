@@ -1424,7 +1424,12 @@ size_t expand_gram_floats(const TfnasCellDesc& d) { return (size_t)(d.ic + 4) * 
 int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch, size_t scratch_floats, float* gram,
                        hipStream_t s) {
     ProfScope _prof(TK_SMALL, s);
-    if (!(d.route & TFNAS_ROUTE_GRAM2)) {
+    int mtot = 0;
+    for (int g = 0; g < d.G; ++g) mtot += d.g[g].mc;
+    // policy (measured, B = 128, alternating bench runs): with the K of ONE candidate (the sampled launches of the w-step, the head)
+    // the single launch wins (w-step -0.1 ms); with all eight candidates' K (4 000 mid channels: 250 MFMA steps per wave) the
+    // split-K GEMM + reduction is faster (alpha-step +0.3 ms with k_gram1)
+    if (!(d.route & TFNAS_ROUTE_GRAM2) && mtot <= 1536) {
         // one launch, no K-split partials, no reduction (k_gram1); `scratch` is not used
         for (int g = 0; g < d.G; ++g)
             if (d.g[g].mc < 1) return TFNAS_EINVAL;

@@ -12,6 +12,7 @@ weight grads of the sampled paths in the w-step (~35 MB, RCCL over xGMI), the 16
 Gradient clipping runs after the reduction, on the averaged gradients (train_search.py:383-384,416-417).
 """
 import os
+import sys
 import random
 
 import numpy as np
@@ -113,8 +114,7 @@ class SearchState:
         # Garbage collection can run at any point of a training loop and at interpreter shutdown: no device-wide synchronisation
         # and no CUDA calls while the interpreter is finalizing (the process teardown frees everything); a failure is reported,
         # not swallowed
-        import sys
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():          # (module globals are cleared at shutdown)
             return
         try:
             self.release(collected=True)
