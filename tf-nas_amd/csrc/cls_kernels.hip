@@ -11,38 +11,55 @@
 #include "kernels.h"
 #include "prof.h"
 
-// One workgroup per image.  pooled[n] is staged in LDS; wave w takes classes w, w + 4, ... in batches of CB (their W rows' loads in
-// flight together), lanes stride the C features in float4 pieces; then softmax / loss in one wave, then d pooled = d logits . W with
-// a thread per feature column (coalesced W rows, d logits from LDS).
-constexpr int CLS_CB = 5;
-__global__ __launch_bounds__(256) void k_cls_ce(int C, int K, const float* __restrict__ pooled, const float* __restrict__ W,
-                                                const float* __restrict__ bias, const int64_t* __restrict__ target, float scale,
-                                                float* __restrict__ logits, float* __restrict__ loss_n,
-                                                float* __restrict__ dlogits, float* __restrict__ dpooled) {
+// One workgroup of 16 waves per image (the launch sits on the step's critical chain with nothing beside it: latency rounds, not
+// occupancy, are what counts -- a first 4-wave version took 45 us, five dependent load rounds per class batch).  pooled[n] is staged
+// in LDS; wave w takes classes w, w + 16, ... in batches of CB with every W load of a batch in flight before the first FMA, lanes
+// stride the C features in float4 pieces; softmax / loss in one wave; then d pooled = d logits . W with the K classes split over
+// KG thread groups (a thread owns four feature columns x one class range, partial sums combined through LDS in group order).
+constexpr int CLS_CB = 4, CLS_T = 1024;
+__global__ __launch_bounds__(CLS_T) void k_cls_ce(int C, int K, int KG, const float* __restrict__ pooled, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, const int64_t* __restrict__ target, float scale,
+                                                  float* __restrict__ logits, float* __restrict__ loss_n,
+                                                  float* __restrict__ dlogits, float* __restrict__ dpooled) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xs = sm;              // [C]
-    float* lg = sm + C;          // [K] logits, then d logits
+    float* xs = sm;                          // [C]
+    float* lg = sm + C;                      // [K rounded up to 4] logits, then d logits
+    float* pp = lg + ((K + 3) & ~3);         // [KG][C] partial d pooled
     const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = CLS_T / 64;
     const float* xp = pooled + (size_t)n * C;
-    for (int c = 4 * tid; c < C; c += 1024) st4(xs + c, ld4(xp + c));
+    for (int c = 4 * tid; c < C; c += 4 * CLS_T) st4(xs + c, ld4(xp + c));
     __syncthreads();
-    for (int k0 = wave * CLS_CB; k0 < K; k0 += 4 * CLS_CB) {
+    for (int k0 = wave; k0 < K; k0 += NW * CLS_CB) {
         float acc[CLS_CB];
 #pragma unroll
         for (int u = 0; u < CLS_CB; ++u) acc[u] = 0.f;
-        for (int c = 4 * lane; c < C; c += 256) {
-            const f32x4 xv = ld4(xs + c);
-            f32x4 wv[CLS_CB];
+        for (int c0 = 0; c0 < C; c0 += 1024) {
+            // four float4 pieces per lane and class (1024 features per round: C = 1280 is two rounds, the second mostly masked)
+            f32x4 wv[CLS_CB][4];
 #pragma unroll
-            for (int u = 0; u < CLS_CB; ++u) wv[u] = ld4(W + (size_t)min(k0 + u, K - 1) * C + c);
+            for (int u = 0; u < CLS_CB; ++u) {
+                const float* wr = W + (size_t)min(k0 + NW * u, K - 1) * C;
 #pragma unroll
-            for (int u = 0; u < CLS_CB; ++u)
-                acc[u] = fmaf(xv.x, wv[u].x, fmaf(xv.y, wv[u].y, fmaf(xv.z, wv[u].z, fmaf(xv.w, wv[u].w, acc[u]))));
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 256 * q + 4 * lane;
+                    wv[u][q] = ld4(wr + (c < C ? c : 0));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + 256 * q + 4 * lane;
+                const f32x4 xv = c < C ? ld4(xs + c) : zero4();
+#pragma unroll
+                for (int u = 0; u < CLS_CB; ++u)
+                    acc[u] = fmaf(xv.x, wv[u][q].x, fmaf(xv.y, wv[u][q].y, fmaf(xv.z, wv[u][q].z, fmaf(xv.w, wv[u][q].w, acc[u]))));
+            }
         }
 #pragma unroll
         for (int u = 0; u < CLS_CB; ++u) {
             const float v = wave_sum(acc[u]);
-            if (lane == 0 && k0 + u < K) lg[k0 + u] = v + (bias ? bias[k0 + u] : 0.f);
+            const int k = k0 + NW * u;
+            if (lane == 0 && k < K) lg[k] = v + (bias ? bias[k] : 0.f);
         }
     }
     __syncthreads();
@@ -69,10 +86,37 @@ __global__ __launch_bounds__(256) void k_cls_ce(int C, int K, const float* __res
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a = 0.f;
-        for (int k = 0; k < K; ++k) a = fmaf(lg[k], W[(size_t)k * C + c], a);
-        dpooled[(size_t)n * C + c] = a;
+    const int nq = C >> 2, kper = (K + KG - 1) / KG;
+    for (int it = tid; it < nq * KG; it += CLS_T) {
+        const int cq = it % nq, kg = it / nq;
+        const int kb = kg * kper, ke = min(K, kb + kper);
+        f32x4 a = zero4();
+        int k = kb;
+        for (; k + 8 <= ke; k += 8) {
+            f32x4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = ld4(W + (size_t)(k + u) * C + 4 * cq);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float g = lg[k + u];
+                a.x = fmaf(g, wv[u].x, a.x); a.y = fmaf(g, wv[u].y, a.y); a.z = fmaf(g, wv[u].z, a.z); a.w = fmaf(g, wv[u].w, a.w);
+            }
+        }
+        for (; k < ke; ++k) {
+            const f32x4 wv = ld4(W + (size_t)k * C + 4 * cq);
+            const float g = lg[k];
+            a.x = fmaf(g, wv.x, a.x); a.y = fmaf(g, wv.y, a.y); a.z = fmaf(g, wv.z, a.z); a.w = fmaf(g, wv.w, a.w);
+        }
+        st4(pp + (size_t)kg * C + 4 * cq, a);
+    }
+    __syncthreads();
+    for (int cq = tid; cq < nq; cq += CLS_T) {
+        f32x4 a = ld4(pp + 4 * cq);
+        for (int kg = 1; kg < KG; ++kg) {
+            const f32x4 b = ld4(pp + (size_t)kg * C + 4 * cq);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        st4(dpooled + (size_t)n * C + 4 * cq, a);
     }
 }
 
@@ -166,12 +210,19 @@ __global__ __launch_bounds__(256) void k_add_into(float* __restrict__ dst, const
 extern "C" int tfnas_cls_ce(int N, int C, int K, const float* pooled, const float* W, const float* bias, const int64_t* target,
                             float scale, float* logits, float* loss_n, float* dlogits, float* dpooled, void* stream) {
     if (!pooled || !W || !target || !logits || !loss_n || !dlogits || !dpooled) return TFNAS_ENULL;
-    if (N < 1 || K < 1 || K > 4096 || C < 4 || C > 8192) return TFNAS_ERANGE;
+    if (N < 1 || K < 1 || K > 4096 || C < 4 || C > 4096) return TFNAS_ERANGE;
     if (C & 3) return TFNAS_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope _prof(TK_SMALL, s);
-    const size_t shm = (size_t)(C + K) * sizeof(float);
-    hipLaunchKernelGGL(k_cls_ce, dim3(N), dim3(256), shm, s, C, K, pooled, W, bias, target, scale, logits, loss_n, dlogits, dpooled);
+    // class groups of the d pooled phase: as many as fill the 1024 threads with (four feature columns x class range) items
+    int KG = CLS_T / (C >> 2);
+    if (KG < 1) KG = 1;
+    if (KG > 8) KG = 8;
+    if (KG > K) KG = K;
+    const size_t shm = ((size_t)C + ((K + 3) & ~3) + (size_t)KG * C) * sizeof(float);
+    if (shm > 64 * 1024) return TFNAS_ERANGE;
+    hipLaunchKernelGGL(k_cls_ce, dim3(N), dim3(CLS_T), shm, s, C, K, KG, pooled, W, bias, target, scale, logits, loss_n, dlogits,
+                       dpooled);
     return (int)hipGetLastError();
 }
 

@@ -923,12 +923,17 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
 // G | b is tiny (ic <= 320, K = all mid channels: 6..130 MFLOP) and sits on the data-gradient chain of EVERY cell between the
 // BN1-backward reduction and k_expand_dgrad; as a 128-row LDS-tiled GEMM split over K plus a k_reduce_rows launch it cost 13..28 us
 // + 5 us per cell (w-step trace, round 6: 40 + 40 launches, 0.9 ms of chain time per w-step).  Here a workgroup owns a 16 x 32 tile
-// of the output; its four waves take every fourth group of 4 mid channels, a lane loads its own MFMA operands straight from W
+// of the output; its sixteen waves take batches of 32 mid channels round-robin, a lane loads its own MFMA operands straight from W
 // (A[i][k] = s_k W[k][r0 + i], B[k][j] = W[k][c0 + j]: 64-byte row pieces, W stays in L2), a batch of GB steps' loads is in flight
-// before their v_mfma_f32_16x16x4_f32; the four partial tiles are summed in double through LDS in wave order (deterministic).
-constexpr int GRAM1_GB = 6;
-__global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __restrict__ cb1, float* __restrict__ gram) {
-    __shared__ float part[4][2][16][17];
+// before their v_mfma_f32_16x16x4_f32; the sixteen waves' partial tiles are summed in double through LDS in wave order
+// (deterministic).  The kernel is bound by its dependent load rounds (~1.5 us each): a first version with four waves took 25 us on
+// the head (K = 1280: 14 rounds per wave); with 16 waves x 8 steps a round covers 512 mid channels.
+#ifndef GRAM1_MAX_K
+#define GRAM1_MAX_K 1536
+#endif
+constexpr int GRAM1_GB = 8, GRAM1_NW = 16;
+__global__ __launch_bounds__(64 * GRAM1_NW) void k_gram1(TfnasCellDesc d, const float* __restrict__ cb1, float* __restrict__ gram) {
+    __shared__ float part[GRAM1_NW][2][16][17];
     const int ic = d.ic;
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, kq = lane >> 4;
@@ -937,11 +942,16 @@ __global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __r
     const bool row_w = r < ic, row_b = r == ic, oka = ca < ic, okb = cb_ < ic;
     const int ra = row_w ? r : 0, caa = oka ? ca : 0, cbb = okb ? cb_ : 0;      // clamped addresses, values masked below
     f32x4 acc0 = zero4(), acc1 = zero4();
+    // the waves take batches of GB steps (4 mid channels each) round-robin over the concatenation of all groups' steps
+    int base = 0;                                   // batches before this group
     for (int g = 0; g < d.G; ++g) {
         const float* __restrict__ W = d.g[g].w_expand;
         const int mc = d.g[g].mc, off = d.g[g].off;
-        const int nstep = (mc + 3) >> 2;
-        for (int s0 = wave * GRAM1_GB; s0 < nstep; s0 += 4 * GRAM1_GB) {
+        const int nstep = (mc + 3) >> 2, nbatch = (nstep + GRAM1_GB - 1) / GRAM1_GB;
+        // first batch of this group that belongs to this wave: (base + b) % NW == wave
+        int b = (wave - base % GRAM1_NW + GRAM1_NW) % GRAM1_NW;
+        for (; b < nbatch; b += GRAM1_NW) {
+            const int s0 = b * GRAM1_GB;
             float a[GRAM1_GB], b0[GRAM1_GB], b1[GRAM1_GB];
             f32x4 t[GRAM1_GB];
 #pragma unroll
@@ -957,7 +967,7 @@ __global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __r
 #pragma unroll
             for (int u = 0; u < GRAM1_GB; ++u) {
                 const int m = 4 * (s0 + u) + kq;
-                const bool okm = m < mc && s0 + u < nstep;
+                const bool okm = m < mc;
                 const float sk = t[u].y * t[u].y * t[u].w;
                 float av = row_w ? sk * a[u] : (row_b ? sk * t[u].x - t[u].y * t[u].z : 0.f);
                 av = okm ? av : 0.f;
@@ -966,6 +976,7 @@ __global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __r
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv1, acc1, 0, 0, 0);
             }
         }
+        base += nbatch;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -973,11 +984,11 @@ __global__ __launch_bounds__(256) void k_gram1(TfnasCellDesc d, const float* __r
         part[wave][1][4 * kq + q][li] = acc1[q];
     }
     __syncthreads();
+    if (tid < 512) {
+        const int h = tid >> 8, row = (tid >> 4) & 15, col = tid & 15;
+        double v = 0.0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = tid >> 4, col = tid & 15;
-        const double v = ((double)part[0][h][row][col] + (double)part[1][h][row][col]) +
-                         ((double)part[2][h][row][col] + (double)part[3][h][row][col]);
+        for (int w = 0; w < GRAM1_NW; ++w) v += (double)part[w][h][row][col];          // (wave order: deterministic)
         const int rr = r0 + row, cc = c0 + 16 * h + col;
         if (rr <= ic && cc < ic) gram[(size_t)rr * ic + cc] = (float)v;
     }
@@ -1427,13 +1438,13 @@ int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch,
     int mtot = 0;
     for (int g = 0; g < d.G; ++g) mtot += d.g[g].mc;
     // policy (measured, B = 128, alternating bench runs): with the K of ONE candidate (the sampled launches of the w-step, the head)
-    // the single launch wins (w-step -0.1 ms); with all eight candidates' K (4 000 mid channels: 250 MFMA steps per wave) the
-    // split-K GEMM + reduction is faster (alpha-step +0.3 ms with k_gram1)
-    if (!(d.route & TFNAS_ROUTE_GRAM2) && mtot <= 1536) {
+    // the single launch wins; with all eight candidates' K (4 000 mid channels: 8 dependent load rounds per wave) it is at best equal
+    // to the split-K GEMM + reduction (a 4-wave version: alpha-step +0.3 ms), which stays for those launches
+    if (!(d.route & TFNAS_ROUTE_GRAM2) && mtot <= GRAM1_MAX_K) {
         // one launch, no K-split partials, no reduction (k_gram1); `scratch` is not used
         for (int g = 0; g < d.G; ++g)
             if (d.g[g].mc < 1) return TFNAS_EINVAL;
-        hipLaunchKernelGGL(k_gram1, dim3(cdiv(d.ic, 32), cdiv(d.ic + 1, 16)), dim3(256), 0, s, d, cb1, gram);
+        hipLaunchKernelGGL(k_gram1, dim3(cdiv(d.ic, 32), cdiv(d.ic + 1, 16)), dim3(64 * GRAM1_NW), 0, s, d, cb1, gram);
         return (int)hipGetLastError();
     }
     const int nt = pick_nt(d.ic, kNtSmall, 6);

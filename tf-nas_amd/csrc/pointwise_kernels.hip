@@ -295,12 +295,26 @@ __global__ __launch_bounds__(256) void k_bn2_gather(TfnasCellDesc d, const float
     const int nq = has_se ? FOLD_Q : 2;
     double acc[FOLD_Q] = {0, 0, 0, 0, 0};
     if (active) {
-        for (int t = t0 + part; t <= t1; t += 4) {
-            const int slot = n - min(t * 128, Po - 1) / HW;
-            const float* r = rec + (((size_t)t * FOLD_SLOTS + slot) * FOLD_Q) * M + off + c0 + cl;
+        // U tiles' records in flight per round (the 112 x 112 stem has 99 tiles per image: 25 dependent rounds per thread group
+        // took 77 us alone on the chip); same summation order as one tile per round (masked tiles add +0.0)
+        constexpr int U = 8;
+        for (int t = t0 + part; t <= t1; t += 4 * U) {
+            float v[U][FOLD_Q];
 #pragma unroll
-            for (int q = 0; q < FOLD_Q; ++q)
-                if (q < nq) acc[q] += (double)r[(size_t)q * M];
+            for (int u = 0; u < U; ++u) {
+                const int tt = min(t + 4 * u, t1);
+                const int slot = n - min(tt * 128, Po - 1) / HW;
+                const float* r = rec + (((size_t)tt * FOLD_SLOTS + slot) * FOLD_Q) * M + off + c0 + cl;
+#pragma unroll
+                for (int q = 0; q < FOLD_Q; ++q) v[u][q] = q < nq ? r[(size_t)q * M] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = t + 4 * u <= t1;
+#pragma unroll
+                for (int q = 0; q < FOLD_Q; ++q)
+                    if (q < nq) acc[q] += ok ? (double)v[u][q] : 0.0;
+            }
         }
     }
 #pragma unroll
