@@ -423,11 +423,13 @@ def run_gpu(args):
         torch.cuda.synchronize()
 
     barrier()
+    ar0 = (search.ALLREDUCE_CALLS, search.ALLREDUCE_BYTES)
     t0 = time.perf_counter()
     for i in range(args.steps):
         pair(args.warmup + 1 + i)
     barrier()
     dt = time.perf_counter() - t0
+    ar1 = (search.ALLREDUCE_CALLS, search.ALLREDUCE_BYTES)
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -470,6 +472,12 @@ def run_gpu(args):
         dist_info = dict(backend=dist.get_backend(), rccl_ranks=dist.get_world_size(), ranks_seen=[r for r, _, _ in rows],
                          w_step_ms_per_rank=[round(w, 3) for _, w, _ in rows], a_step_ms_per_rank=[round(a, 3) for _, _, a in rows],
                          w_step_ms_spread=round(max(w for _, w, _ in rows) - min(w for _, w, _ in rows), 3),
+                         w_step_ms_min_max=[round(min(w for _, w, _ in rows), 3), round(max(w for _, w, _ in rows), 3)],
+                         a_step_ms_min_max=[round(min(a for _, _, a in rows), 3), round(max(a for _, _, a in rows), 3)],
+                         # the gradient exchange of this rank inside the timed region: collectives and payload per iteration pair
+                         # (two weight steps' sampled-path gradients, ~35 MB each, + the 162 architecture scalars)
+                         allreduce_calls_per_pair=round((ar1[0] - ar0[0]) / max(1, args.steps), 2),
+                         allreduce_bytes_per_pair=int((ar1[1] - ar0[1]) / max(1, args.steps)),
                          gpu_max_hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'))
         # replica consistency (tools/dp_check.py's hash): every rank hashes all of its parameters after the
         # timed region; data-parallel replicas must be bit-identical
@@ -745,8 +753,13 @@ def dry_rank():
     dist.init_process_group('gloo', rank=rank, world_size=world)
     t = torch.ones(1)
     dist.all_reduce(t)
+    # the shape of the real line's `dist` object: one row per rank, gathered (here: rank ids only)
+    mine = torch.tensor([float(rank)])
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
     if rank == 0:
-        print(json.dumps(dict(dry_run=True, n_gpus=world, ranks_seen=int(t.item()), argv=sys.argv[1:])), flush=True)
+        print(json.dumps(dict(dry_run=True, n_gpus=world, ranks_seen=int(t.item()), rank_ids=sorted(int(r.item()) for r in rows),
+                              argv=sys.argv[1:])), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

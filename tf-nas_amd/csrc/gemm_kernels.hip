@@ -1296,6 +1296,12 @@ int launch_expand_fwd(const TfnasCellDesc& d, const float* x, float* E, double* 
     return launch_reduce_rows(part, grid.x, 2 * d.M, 2 * (size_t)d.M, stats1, nullptr, s);
 }
 
+#ifndef TFNAS_WSPLIT_DGRAD
+#define TFNAS_WSPLIT_DGRAD 2
+#endif
+#ifndef TFNAS_WSPLIT_PFWD
+#define TFNAS_WSPLIT_PFWD 2
+#endif
 int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate, const double* stats2,
                        float* Pr, double* stats3, float* part, hipStream_t s) {
     ProfScope _prof(TK_PROJECT_FWD, s);
@@ -1313,6 +1319,7 @@ int launch_project_fwd(const TfnasCellDesc& d, const float* D, const float* gate
         nsplit = cdiv(1024, wgs);
         if (nsplit > 4) nsplit = 4;
         if (nsplit > kch / 8) nsplit = kch / 8;
+        if (d.need_wgrad && d.G == 1 && nsplit > TFNAS_WSPLIT_PFWD) nsplit = TFNAS_WSPLIT_PFWD;      // (see expand_dgrad_splits)
         const size_t per = (size_t)d.G * Po * d.oc, rows2 = 256 * (size_t)ncols2;
         while (nsplit > 1 && (nsplit - 1) * per + rows2 > TFNAS_PART_FLOATS) --nsplit;
     }
@@ -1425,6 +1432,10 @@ int expand_dgrad_splits(const TfnasCellDesc& d) {
     int ns = cdiv(1024, tiles);
     if (ns > 16) ns = 16;
     if (ns > nchunks / 4) ns = nchunks / 4;      // at least 4 K-chunks per split
+    // one-candidate launches of the weight step run beside three other queues: the chip is full anyway, and every extra split is
+    // one more [P][ic] partial written, read back and summed (k_dx_reduce).  Capped at 2 (round 6, four alternating bench pairs on
+    // one box: w-step 16.55 -> 16.37 ms; a cap of 1 loses: the 196-tile launches of the 14 x 14 cells then walk 40+ K-chunks each)
+    if (d.need_wgrad && d.G == 1 && ns > TFNAS_WSPLIT_DGRAD) ns = TFNAS_WSPLIT_DGRAD;
     return ns < 1 ? 1 : ns;
 }
 

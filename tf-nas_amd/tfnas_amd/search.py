@@ -226,7 +226,9 @@ class SearchState:
         stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         _lib.check(_lib.lib().tfnas_pack_ranges(_lib.ptr(a.g), _lib.ptr(self._msg), nspans, arr[0], arr[1], arr[2], stream),
                    'tfnas_pack_ranges')
+        global ALLREDUCE_BYTES
         ALLREDUCE_CALLS += 1
+        ALLREDUCE_BYTES += 4 * int(n)
         return dist.all_reduce(self._msg[lo:lo + n], op=dist.ReduceOp.SUM, group=self._dp['group'], async_op=async_op)
 
     def _dp_hook(self, cur, side):
@@ -293,6 +295,8 @@ class SearchState:
                 self._check_same_architecture(idx_lists, group)
                 dist.all_reduce(self._msg[:total], op=dist.ReduceOp.SUM, group=group)
                 ALLREDUCE_CALLS += 1
+                global ALLREDUCE_BYTES
+                ALLREDUCE_BYTES += 4 * int(total)
                 g, scale = self._msg, 1.0 / world
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         nblk = sum((sp[1] + 8191) // 8192 for sp in spans)
@@ -601,6 +605,7 @@ HOST_SAMPLING = True                    # w_step: gumbel positions from the stag
 FORCE_ALLREDUCE_AT_WORLD_1 = os.environ.get('TFNAS_FORCE_ALLREDUCE', '0') == '1'
 _TINY = float(np.finfo(np.float32).tiny)
 ALLREDUCE_CALLS = 0                    # collectives issued by this process (tests / tools/dp_check.py)
+ALLREDUCE_BYTES = 0                    # ... and the payload bytes they carried (bench.py: bytes per iteration pair and rank)
 
 
 def allreduce_mean_(tensors, group=None):
@@ -610,9 +615,10 @@ def allreduce_mean_(tensors, group=None):
         return
     if dist.get_world_size(group) == 1 and not FORCE_ALLREDUCE_AT_WORLD_1:
         return
-    global ALLREDUCE_CALLS
+    global ALLREDUCE_CALLS, ALLREDUCE_BYTES
     ALLREDUCE_CALLS += 1
     flat = torch.cat([t.reshape(-1) for t in tensors])
+    ALLREDUCE_BYTES += flat.numel() * flat.element_size()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / dist.get_world_size(group))
     # scatter back with ONE multi-tensor copy (a per-tensor copy_ loop is ~300 tiny launches per w-step)
