@@ -440,6 +440,14 @@ int cell_bwd_impl(const TfnasCellDesc& d0, const TfnasCellWs& ws, const CellBwdB
             TRY(launch_expand_gram(d, cb1, part, TFNAS_PART_FLOATS - expand_gram_floats(d), gram, s));
             TRY(launch_expand_dgrad_x(d, b.x, cb1, gram, dout_res, b.wmix, b.dx, b.dEh, nsl, s, b.add_src, b.add_scale));
         }
+#ifdef TFNAS_FXW_TIMING
+        if (d.need_wgrad) {              // timing only (fx_kernels.hip: fx_plan): the materialised route's weight-gradient launches
+            hipStream_t sw = fork_to(so, 1, s);
+            if (d.SE > 0) TRY(launch_se_wgrad(d, dgate, gate, dhpre, hpre, pooled, sw));
+            TRY(launch_dw_wgrad(d, b.dZ, gate, dpooled, b.D, stats2, red2, b.E, stats1, part_w1, sw));
+            TRY(launch_expand_wgrad(d, b.dEh, b.E, cb1, b.x, part_w2, fork_to(so, 2, s)));
+        }
+#endif
         return 0;
     }
     // stride-1 ring cells: the depthwise weight gradient comes out of the backward-data pass below (same dd window, same E

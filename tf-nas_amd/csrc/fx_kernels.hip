@@ -53,7 +53,15 @@ extern "C" int tfnas_dbg_fx_timing(unsigned long long* out, int n) {
 static int fx_ks(int ic) { return (ic + 31) / 32; }
 
 bool fx_plan(const TfnasCellDesc& d, FxPlan& pl, bool bwd) {
+#ifdef TFNAS_FXW_TIMING
+    // TIMING-ONLY build (tools/r6_fxw.sh): the fused per-image route also for launches that want weight
+    // gradients -- the existing weight-gradient kernels then read ehat as if it were E and the dx-partial scratch as if it were dE
+    // (wrong numerics by construction; never shipped, never tested for parity): what would the sampled late cells of the w-step
+    // gain from a fused route BEFORE anybody builds its weight gradients?
+    if (d.mode != TFNAS_MODE_CELL) return false;
+#else
     if (d.mode != TFNAS_MODE_CELL || d.need_wgrad) return false;
+#endif
     if (stats_sync_on(d)) return false;                     // (BN1 statistics come from the Gram matrix of x: efree_kernels.hip)
     if (d.ic < 64 || d.ic > 192 || (d.ic & 15)) return false;
     if (d.stride != 1) return false;                       // (stride-2 cells keep the materialised route)
