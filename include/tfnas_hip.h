@@ -14,8 +14,9 @@
  *    scratch; sizes come from tfnas_cell_ws();
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *  - return value: 0 ok, <0 invalid argument (TFNAS_E*), >0 a hipError_t;
- *  - re-entrant per stream; every mode a launch runs in can be given in its descriptor (gemm_mode, flags, sync_fn).  The only
- *    process-global state is the DEFAULTS of those modes (tfnas_set_gemm_mode / _lazy_join / _stats_sync), a registry of library-owned side streams (one per
+ *  - re-entrant per stream; every mode and every kernel-variant choice of a launch is given in its descriptor (gemm_mode, flags,
+ *    route, sync_fn); the library reads no environment variable.  The only
+ *    process-global state is the DEFAULTS of three modes (tfnas_set_gemm_mode / _lazy_join / _stats_sync), a registry of library-owned side streams (one per
  *    caller stream and device, created on first use by tfnas_mixedop_bwd with need_wgrad; released by
  *    tfnas_shutdown()) and the opt-in tfnas_prof_* timers; results never depend on either.
  *
@@ -478,7 +479,7 @@ int tfnas_arch_adam_project(int n, float *const *p, const float *const *g, const
  * (2) call tfnas_side_join(stream) before anything on `stream` reads the weight gradients (the optimizer step).
  * (train_eval.py:228-252 has no such notion: one stream; this is scheduling only, the results are bit-identical.) */
 int tfnas_set_lazy_join(int on);
-int tfnas_side_stream(void *stream, void **side);   /* *side = the side stream paired with `stream` (NULL: TFNAS_WGRAD_STREAM=0) */
+int tfnas_side_stream(void *stream, void **side);   /* *side = the library-owned side stream paired with `stream` (created on first use) */
 int tfnas_side_join(void *stream);
 
 /* ---- arithmetic of the 1x1-convolution GEMMs --------------------------------------------------------------------------------
@@ -490,7 +491,8 @@ int tfnas_side_join(void *stream);
  *   TFNAS_GEMM_X2   (3)           three products (error ~2^-16)
  *   TFNAS_GEMM_BF16 (1)           plain bf16 operands, fp32 accumulation (the reduced-precision mode of the derived network's
  *                                 training step; train_eval_amp.py:176-180 in the reference)
- * Process-wide; the environment variable TFNAS_GEMM = x3 | f32 | x2 | bf16 sets the initial value.  Returns TFNAS_EINVAL for
+ * Process-wide default (TFNAS_GEMM_X3 until set; the library reads no environment variable -- the Python mirror passes TFNAS_GEMM =
+ * x3 | f32 | x2 | bf16 on to this call when it loads the library); a descriptor's own gemm_mode wins.  Returns TFNAS_EINVAL for
  * any other mode.  tfnas_gemm_mode() returns the current one. */
 #define TFNAS_GEMM_F32 0
 #define TFNAS_GEMM_BF16 1
