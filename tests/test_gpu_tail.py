@@ -152,3 +152,41 @@ def test_fused_tail_is_bit_deterministic_and_leaves_module_api_usable():
     F.cross_entropy(logits, y).backward()
     g = ma.first_stem.conv.weight.grad
     assert g is not None and float(g.abs().max()) > 0
+
+
+def test_frozen_classifier_loss_function_matches_torch_autograd():
+    """tail.ClsCeFn (the architecture step's classifier + cross-entropy in one launch): loss, logits and the gradient w.r.t. the pooled
+    features under an arbitrary upstream gradient, against F.linear + F.cross_entropy."""
+    from tfnas_amd.tail import ClsCeFn
+    g = torch.Generator().manual_seed(21)
+    N, Cf, K = 16, 1280, 100
+    W = (torch.randn(K, Cf, generator=g) * 0.05).cuda()
+    b = (torch.randn(K, generator=g) * 0.1).cuda()
+    x = torch.randn(N, Cf, generator=g).cuda()
+    t = torch.randint(0, K, (N,), generator=g).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    la = F.cross_entropy(F.linear(xa, W, b), t)
+    (2.5 * la).backward()
+    lb, logits = ClsCeFn.apply(xb, W, b, t)
+    (2.5 * lb).backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 + 1e-5 * abs(float(la))
+    _close(logits, F.linear(x, W, b), 'logits')
+    _close(xb.grad, xa.grad, 'd pooled')
+
+
+def test_alpha_step_with_the_one_launch_classifier_loss_equals_the_torch_tail(monkeypatch):
+    """ONE architecture step from identical state with and without tail.ClsCeFn: losses, latency, the 24 arch gradients."""
+    from tfnas_amd import search
+    ((ma, sa, _, oaa), (mb, sb, _, oab)), x, y = _two_states(seed=4)
+    outs = []
+    for st, oa, on in ((sa, oaa, True), (sb, oab, False)):
+        monkeypatch.setattr(search, 'FUSED_TAIL', on)
+        noise = search.NoiseSource(3)
+        la, ll, lat, grads = search.a_step(st, x, y, oa, 15.0, 0.1, 5.0, noise.exp(x.device), return_grads=True)
+        torch.cuda.synchronize()
+        outs.append((float(la), float(ll), float(lat), grads))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[1][0]) + 1e-6 and outs[0][1:3] == outs[1][1:3]
+    for ga, gb in zip(outs[0][3], outs[1][3]):
+        _close(ga, gb, 'arch gradient', rtol=1e-4, atol=1e-7)
+    for pa, pb in zip(ma.arch_parameters(), mb.arch_parameters()):
+        _close(pa.detach(), pb.detach(), 'arch parameter after the step', rtol=1e-5, atol=1e-6)

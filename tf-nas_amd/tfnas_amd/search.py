@@ -847,7 +847,10 @@ def _a_forward_paths(state, x, noise):
     W, CL = model.arch_weights(feat.size(-1), x.device, noise)
     out, stage_lat = runner.soft(feat, W, CL)
     lat = stage_lat.sum() + model.lat_lookup['base']
-    return model.classifier(model._head(out)), lat
+    pooled = model._head(out)
+    if FUSED_TAIL:
+        return pooled, lat                           # (a_step: logits + cross-entropy + d pooled in ONE launch, tail.ClsCeFn)
+    return model.classifier(pooled), lat
 
 
 def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5.0, noise=None, group=None,
@@ -857,11 +860,21 @@ def a_step(state, x, target, opt_a, target_lat=15.0, lambda_lat=0.1, grad_clip=5
     model = state.model
     state.throttle(x.device)
     state.require(False, True)
+    loss_a = None
     if state.runner is not None and USE_PATHS:
         logits, lat = _a_forward_paths(state, x, noise)
+        if FUSED_TAIL:                               # (`logits` is the pooled feature vector here)
+            from .tail import frozen_classifier_loss
+            pooled = logits
+            res = frozen_classifier_loss(model, pooled, target)
+            if res is not None:
+                loss_a, logits = res
+            else:
+                logits = model.classifier(pooled)
     else:
         logits, lat = model(x, False, exp_noise=noise)
-    loss_a = F.cross_entropy(logits, target)
+    if loss_a is None:
+        loss_a = F.cross_entropy(logits, target)
     loss_l = torch.abs(lat / target_lat - 1.) * lambda_lat
     loss = loss_a + loss_l
     opt_a.zero_grad()

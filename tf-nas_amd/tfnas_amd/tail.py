@@ -154,6 +154,48 @@ class BiTailFn(torch.autograd.Function):
         return None, None, ctx.dxa.permute(0, 3, 1, 2), ctx.dxb.permute(0, 3, 1, 2), None, None, None
 
 
+class ClsCeFn(torch.autograd.Function):
+    """(loss, logits) = cross_entropy(linear(pooled, W, b), target), mean reduction, for FROZEN classifier weights (the architecture
+    step, ``validate``): ONE launch forward (tfnas_cls_ce: logits, per-image loss, d logits, d pooled) + a 128-element sum, one
+    scaling launch backward -- instead of eight stock torch launches (GEMM, log-softmax, nll and their backward kernels).
+    Reference: models/model_search.py:301-303 + train_search.py:107,410."""
+
+    @staticmethod
+    def forward(ctx, pooled, W, b, target):
+        lib = _lib.lib()
+        pooled = pooled.contiguous()
+        N, Cf = pooled.shape
+        K = W.shape[0]
+        dev = pooled.device
+        if target.dtype != torch.int64 or not target.is_contiguous():
+            target = target.long().contiguous()
+        logits = torch.empty((N, K), device=dev, dtype=torch.float32)
+        loss_n = torch.empty(N, device=dev, dtype=torch.float32)
+        dlogits = torch.empty((N, K), device=dev, dtype=torch.float32)
+        dpooled = torch.empty((N, Cf), device=dev, dtype=torch.float32)
+        with _on(dev):
+            check(lib.tfnas_cls_ce(N, Cf, K, ptr(pooled), ptr(W), ptr(b), ptr(target), 1.0 / N, ptr(logits), ptr(loss_n),
+                                   ptr(dlogits), ptr(dpooled), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'tfnas_cls_ce')
+        ctx.save_for_backward(dpooled)
+        ctx.mark_non_differentiable(logits)
+        return loss_n.sum() * (1.0 / N), logits
+
+    @staticmethod
+    def backward(ctx, gloss, glogits):
+        dpooled, = ctx.saved_tensors
+        return dpooled * gloss, None, None, None
+
+
+def frozen_classifier_loss(model, pooled, target):
+    """loss, logits through ClsCeFn when the classifier's parameters are frozen CUDA fp32 tensors; None otherwise."""
+    lin = getattr(getattr(model, 'classifier', None), 'linear', None)
+    if lin is None or lin.bias is None or lin.weight.requires_grad or lin.bias.requires_grad or not pooled.is_cuda:
+        return None
+    if lin.weight.dtype != torch.float32 or (lin.in_features & 3) or lin.in_features > 4096 or lin.out_features > 4096:
+        return None
+    return ClsCeFn.apply(pooled, lin.weight.detach(), lin.bias.detach(), target)
+
+
 def _clone_on(t, stream):
     with torch.cuda.stream(stream):
         c = t.clone()
