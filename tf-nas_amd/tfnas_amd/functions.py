@@ -171,6 +171,9 @@ class CellPlan:
         self.mode = mode
         self.has_res = int(mode == _lib.MODE_CELL and ic == oc and stride == 1)
         self._desc_cache = {}
+        # set by search.SearchState.stem_direct around the backward of a path-level weight step (the stem cell's plan only):
+        self.grad_targets = None       # tensors the backward writes the weight gradients INTO (arena views); autograd then gets None
+        self.wgrad_streams = None      # [3] torch streams for the three weight-gradient forks (TfnasCellDesc.wgrad_stream) or None
 
     def params(self):
         ps = []
@@ -270,7 +273,7 @@ def _cell_backward(ctx, dout, want_dx):
     need_w = any(ctx.needs_input_grad[3:])
     # plan.grad_targets (set by search._w_step_paths around its backward): the kernels write the weight gradients straight into
     # these tensors (the WeightArena's views) and autograd gets None for them -- no temporaries, no AccumulateGrad adds
-    direct = getattr(plan, 'grad_targets', None) if need_w else None
+    direct = plan.grad_targets if need_w else None
     if direct is not None and (len(direct) != len(params) or any(g.shape != p.shape or g.device != p.device or not g.is_contiguous()
                                                                  for g, p in zip(direct, params))):
         raise RuntimeError('tfnas_amd: grad_targets do not match the parameters of this launch')
@@ -283,7 +286,7 @@ def _cell_backward(ctx, dout, want_dx):
     bsmall = torch.empty(ws.bsmall, device=dev, dtype=torch.float32)
     red = torch.empty(ws.red, device=dev, dtype=torch.float64)
     # with weight gradients the library wants twice the scratch (second half: its weight-gradient side stream)
-    ws_streams = getattr(plan, 'wgrad_streams', None) if need_w else None    # (stem cell of the weight step: search.SearchState hands in idle queues)
+    ws_streams = plan.wgrad_streams if need_w else None    # (stem cell of the weight step: search.SearchState hands in idle queues)
     part = _part(ws.part * (4 if ws_streams else (2 if need_w else 1)), dev)    # (own scratch per fork on its own stream)
     dx = torch.empty((N, d.H, d.W, plan.ic), device=dev, dtype=torch.float32) if want_dx else None
     dxp = torch.empty(ws.dxp, device=dev, dtype=torch.float32) if want_dx else None
