@@ -23,9 +23,10 @@ def _model(lut, seed=2, T=5.0):
 
 def _run(lut, use_paths, pairs=2, B=8, warm=False):
     from tfnas_amd import search
-    old, old_f = search.USE_PATHS, search.FUSED_OPT
+    old, old_f, old_t = search.USE_PATHS, search.FUSED_OPT, search.FUSED_TAIL
     search.USE_PATHS = use_paths
     search.FUSED_OPT = False               # (same torch.optim tail on both sides: this test is about the path level)
+    search.FUSED_TAIL = False              # (... and the same stock classifier + cross-entropy: tests/test_gpu_tail.py covers tail.py)
     try:
         m = _model(lut)
         st = search.SearchState(m)
@@ -50,7 +51,7 @@ def _run(lut, use_paths, pairs=2, B=8, warm=False):
         torch.cuda.synchronize()
         return {k: p.detach().clone() for k, p in m.named_parameters()}, lats
     finally:
-        search.USE_PATHS, search.FUSED_OPT = old, old_f
+        search.USE_PATHS, search.FUSED_OPT, search.FUSED_TAIL = old, old_f, old_t
 
 
 @pytest.mark.parametrize('warm', [False, True])
