@@ -136,6 +136,7 @@ class SearchState:
                     torch.cuda.synchronize()            # (kernels of the side streams may still use the arenas)
                 self.runner.close()
         self.runner = None
+        self._bitail = None                         # (the fused tail's persistent buffers go with the arenas)
         m = self.model
         if m is not None and m.__dict__.get('_pstate') is self:
             m.__dict__.pop('_pstate', None)
