@@ -923,15 +923,18 @@ __global__ __launch_bounds__(256) void k_expand_gram(TfnasCellDesc d, const floa
 // G | b is tiny (ic <= 320, K = all mid channels: 6..130 MFLOP) and sits on the data-gradient chain of EVERY cell between the
 // BN1-backward reduction and k_expand_dgrad; as a 128-row LDS-tiled GEMM split over K plus a k_reduce_rows launch it cost 13..28 us
 // + 5 us per cell (w-step trace, round 6: 40 + 40 launches, 0.9 ms of chain time per w-step).  Here a workgroup owns a 16 x 32 tile
-// of the output; its sixteen waves take batches of 32 mid channels round-robin, a lane loads its own MFMA operands straight from W
+// of the output; its waves take batches of 32 mid channels round-robin, a lane loads its own MFMA operands straight from W
 // (A[i][k] = s_k W[k][r0 + i], B[k][j] = W[k][c0 + j]: 64-byte row pieces, W stays in L2), a batch of GB steps' loads is in flight
-// before their v_mfma_f32_16x16x4_f32; the sixteen waves' partial tiles are summed in double through LDS in wave order
-// (deterministic).  The kernel is bound by its dependent load rounds (~1.5 us each): a first version with four waves took 25 us on
-// the head (K = 1280: 14 rounds per wave); with 16 waves x 8 steps a round covers 512 mid channels.
+// before their v_mfma_f32_16x16x4_f32; the waves' partial tiles are summed in double through LDS in wave order
+// (deterministic).  The kernel is bound by its dependent load rounds (~1.5 us each).
 #ifndef GRAM1_MAX_K
 #define GRAM1_MAX_K 1536
 #endif
-constexpr int GRAM1_GB = 8, GRAM1_NW = 16;
+constexpr int GRAM1_GB = 8;
+// GRAM1_NW waves per workgroup: 4 inside the cells' backward (four queues keep every CU busy there: a 1 024-thread workgroup waits
+// for a whole CU to drain -- in situ 44 us on average, 400 us worst case, against 17 us for the 256-thread form, rocprofv3 statistics
+// of round 6), 16 for the head (K = 1 280, in the quiet stretch between the paths' forward and backward: 25-70 -> 10 us)
+template <int GRAM1_NW>
 __global__ __launch_bounds__(64 * GRAM1_NW) void k_gram1(TfnasCellDesc d, const float* __restrict__ cb1, float* __restrict__ gram) {
     __shared__ float part[GRAM1_NW][2][16][17];
     const int ic = d.ic;
@@ -984,8 +987,8 @@ __global__ __launch_bounds__(64 * GRAM1_NW) void k_gram1(TfnasCellDesc d, const 
         part[wave][1][4 * kq + q][li] = acc1[q];
     }
     __syncthreads();
-    if (tid < 512) {
-        const int h = tid >> 8, row = (tid >> 4) & 15, col = tid & 15;
+    for (int e = tid; e < 512; e += 64 * GRAM1_NW) {
+        const int h = e >> 8, row = (e >> 4) & 15, col = e & 15;
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < GRAM1_NW; ++w) v += (double)part[w][h][row][col];          // (wave order: deterministic)
@@ -1455,7 +1458,9 @@ int launch_expand_gram(const TfnasCellDesc& d, const float* cb1, float* scratch,
         // one launch, no K-split partials, no reduction (k_gram1); `scratch` is not used
         for (int g = 0; g < d.G; ++g)
             if (d.g[g].mc < 1) return TFNAS_EINVAL;
-        hipLaunchKernelGGL(k_gram1, dim3(cdiv(d.ic, 32), cdiv(d.ic + 1, 16)), dim3(64 * GRAM1_NW), 0, s, d, cb1, gram);
+        const dim3 grid(cdiv(d.ic, 32), cdiv(d.ic + 1, 16));
+        if (d.mode == TFNAS_MODE_HEAD) hipLaunchKernelGGL(k_gram1<16>, grid, dim3(1024), 0, s, d, cb1, gram);
+        else hipLaunchKernelGGL(k_gram1<4>, grid, dim3(256), 0, s, d, cb1, gram);
         return (int)hipGetLastError();
     }
     const int nt = pick_nt(d.ic, kNtSmall, 6);
